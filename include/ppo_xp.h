@@ -1,0 +1,207 @@
+/*
+ * ppo_xp.h — C ABI of the MI355X-native experience path (rollout buffer -> GAE/returns ->
+ * advantage standardisation -> shuffled minibatch gather) of flawedmatrix/ppo.
+ *
+ * The reference has no FFI: the path is a set of crate-private Rust methods
+ * (ppo/src/common/buffer.rs, ppo/src/model/data.rs) called only from train()
+ * (ppo/src/training.rs:114,163,172,186,187,191,205).  Each entry point below names the Rust
+ * method it replaces (paths relative to the reference checkout).  The Rust-side binding a
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returning int: 0 = ok, < 0 = -errno style failure (PPO_XP_E*), and the
+ *     text of the failure is available from ppo_xp_last_error() (thread local).  Nothing
+ *     throws across the ABI.  Where the reference panics (size mismatches) the call fails
+ *     with PPO_XP_EINVAL and changes nothing; a Rust shim turns that back into a panic.
+ *   - a handle is owned by one thread at a time (the reference takes &mut self); distinct
+ *     handles (one per GPU / rank) are independent.
+ *   - all device work of a handle is enqueued on ONE HIP stream (ppo_xp_stream()).  Calls
+ *     that return host data synchronise that stream; all others only enqueue.
+ *   - device pointers handed out stay valid until the next ppo_xp_pass_begin(), a
+ *     ppo_xp_returns() (for returns/advantages) or ppo_xp_destroy().
+ *   - the library is HIP only: there is no CPU fallback.  Creating a handle without a usable
+ *     GPU fails with PPO_XP_ENODEV.
+ */
+#ifndef PPO_XP_H
+#define PPO_XP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PPO_XP_OK 0
+#define PPO_XP_EINVAL (-22) /* size / argument mismatch: the reference would panic      */
+#define PPO_XP_ENOMEM (-12) /* device or host allocation failed                         */
+#define PPO_XP_EIO (-5)     /* a HIP / RCCL call failed (text in ppo_xp_last_error())   */
+#define PPO_XP_ENODEV (-19) /* no usable HIP device                                     */
+#define PPO_XP_ESTATE (-1)  /* call out of order (e.g. pass_begin before returns)       */
+
+/* GAE algorithm selector for ppo_xp_returns(). */
+#define PPO_XP_GAE_SEQUENTIAL 0 /* K1: one lane per env, strict reverse-time order; bit-exact
+                                   with the reference's fp32 op order (buffer.rs:206-222)   */
+#define PPO_XP_GAE_ASSOC 1      /* K2: time-chunked associative linear-recurrence scan with an
+                                   LDS scan over chunk carries; for long horizons / few envs;
+                                   NOT bit-exact (bound stated in DESIGN.md)                 */
+/* bits 16..31 of `algo`, when non-zero, force the chunk length of PPO_XP_GAE_ASSOC. */
+#define PPO_XP_GAE_CHUNK(len) ((int)((unsigned)(len) << 16))
+/* do not build the packed per-transition records the gather reads (GAE-only measurements;
+ * ppo_xp_pass_begin() then builds them itself on first use). */
+#define PPO_XP_GAE_NO_PACK 0x100
+
+typedef struct ppo_xp ppo_xp; /* opaque: replaces ExperienceBuffer + ExperienceBatcher */
+
+/* Device views of the flattened buffer: replaces training_views() (buffer.rs:142-175) and the
+ * master `set` of ExperienceBatcher (data.rs:14-19,63-70).  Flat index i = t*num_envs + e over
+ * rows 0..len in STORAGE order (after a ring wrap this is not chronological, buffer.rs:386-405).
+ * returns/advantages are valid after ppo_xp_returns(). */
+typedef struct ppo_xp_views_t {
+  size_t num_steps;         /* M = len * num_envs                              */
+  size_t obs_size;          /* D                                               */
+  const float *observations;/* [M, D]  f32 device                              */
+  const int64_t *actions;   /* [M]     i64 device (usize in the reference)     */
+  const float *values;      /* [M]                                             */
+  const float *neglogps;    /* [M]                                             */
+  const float *rewards;     /* [M]                                             */
+  const float *dones;       /* [M]  0.0 / 1.0 (buffer.rs:95)                   */
+  const float *returns;     /* [M]  fl(A + v)              (buffer.rs:222)     */
+  const float *advantages;  /* [M]  fl(fl(A + v) - v)      (data.rs:62)        */
+} ppo_xp_views_t;
+
+/* One minibatch on the device: replaces struct ExperienceBatch (data.rs:4-12). */
+typedef struct ppo_batch_view {
+  size_t index;             /* k, 0-based position in the pass                 */
+  size_t batch_size;        /* B                                               */
+  size_t obs_size;          /* D                                               */
+  const float *observations;/* [B, D]                                          */
+  const int64_t *actions;   /* [B]                                             */
+  const float *values;      /* [B]                                             */
+  const float *neglogps;    /* [B]                                             */
+  const float *returns;     /* [B]                                             */
+  const float *advantages;  /* [B] standardised per minibatch (data.rs:157-164)*/
+  float adv_mean;           /* filled only if the caller asked for host stats  */
+  float adv_std;
+} ppo_batch_view;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* ExperienceBuffer::new_with_params (buffer.rs:52-69); `new` (buffer.rs:45-47) is gamma=0.99,
+ * lambda=0.95.  NUM_ENVS / OBS_SIZE are run-time here (const generics in the reference).
+ * Allocates the six zero-filled streams on HIP device `device`. */
+int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, size_t obs_size,
+                  float gamma, float lambda);
+/* Drop of ExperienceBuffer / ExperienceBatcher. */
+void ppo_xp_destroy(ppo_xp *h);
+
+/* ---- insert ---------------------------------------------------------------------------- */
+
+/* ExperienceBuffer::add_experience (buffer.rs:84-121).  Host pointers; obs is [n, obs_size],
+ * the rest [n]; dones are Rust bools (1 byte, 0/1).  n != num_envs => PPO_XP_EINVAL (the
+ * reference panics, buffer.rs:97-112). */
+int ppo_xp_add(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions,
+               const float *vals, const uint8_t *dones, const float *neglogps, size_t n);
+/* `steps` consecutive add_experience calls from [steps, n, ...] host arrays (same ring
+ * semantics as calling ppo_xp_add in a loop; one upload per stream per contiguous run). */
+int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions,
+                    const float *vals, const uint8_t *dones, const float *neglogps, size_t n,
+                    size_t steps);
+/* add_experience with DEVICE source rows (device-resident simulators / policies);
+ * dones_f32 already 0.0/1.0.  Enqueued on the handle's stream. */
+int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions,
+                      const float *vals, const float *dones_f32, const float *neglogps, size_t n);
+
+/* ExperienceBuffer::reset_counter (buffer.rs:131-133): counter = 0, data untouched. */
+void ppo_xp_reset_counter(ppo_xp *h);
+/* ExperienceBuffer::len (buffer.rs:123-129): min(counter, capacity). */
+size_t ppo_xp_len(const ppo_xp *h);
+/* Internal ring state, for tests of buffer.rs:93,115-120. */
+size_t ppo_xp_counter(const ppo_xp *h);
+size_t ppo_xp_last_values_idx(const ppo_xp *h);
+
+/* ---- GAE / returns --------------------------------------------------------------------- */
+
+/* ExperienceBuffer::returns (buffer.rs:187-225) fused with `advantages = returns - values`
+ * of ExperienceBatcher::new (data.rs:62).  last_dones: n Rust bools on the host.  Leaves
+ * returns / advantages resident on the device; if host_out != NULL also copies the len*n
+ * returns to it (synchronises).  n != num_envs => PPO_XP_EINVAL (buffer.rs:194). */
+int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out);
+
+/* ExperienceBuffer::training_views (buffer.rs:142-175) + the batcher's master set. */
+int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out);
+
+/* ---- one shuffled pass over the buffer (IntoIterator + Iterator, data.rs:85-193) ------- */
+
+/* (&batcher).into_iter() (data.rs:91-102) plus the work of every next() of the pass
+ * (data.rs:115-192): takes / draws the permutation, gathers all K = ceil(M/B) minibatches into
+ * contiguous device slabs and standardises each minibatch's advantages.
+ *   perm != NULL : host array of M u32 indices, used as given (must be a permutation of 0..M
+ *                  for reference semantics; every entry is range-checked).
+ *   perm == NULL : the library draws it on the host: rand 0.8.5 Fisher-Yates + u32 gen_range
+ *                  over ChaCha12 seeded like ChaCha12Rng::seed_from_u64(seed) (the reference's
+ *                  thread_rng() is OS-seeded and cannot be reproduced, data.rs:94).
+ * batch_size > M is not an error: the pass is empty (data.rs:117-119).  batch_size == 0 is
+ * PPO_XP_EINVAL (the reference would loop forever on empty batches). */
+int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64_t seed);
+/* Same, with the permutation already on the device (u32[M]).  The array is BORROWED, not copied:
+ * it must stay valid and unchanged until the pass's kernels have run (ppo_xp_sync(), or the next
+ * pass_begin).  Entries are not range-checked; the kernel clamps them to M-1 so that a bad index
+ * can never fault the GPU. */
+int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_dev);
+/* Iterator::next (data.rs:115-192): 0 = *out filled, 1 = exhausted (`None`), < 0 error.
+ * The windows follow data.rs:121-126 exactly, including the overlapping tail batch. */
+int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out);
+/* Number of minibatches of the current pass (ExperienceBatcher::len()/B rounded up). */
+size_t ppo_xp_pass_num_batches(const ppo_xp *h);
+/* The permutation of the current pass on the device (u32[M]) / copied to the host. */
+const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *h);
+int ppo_xp_pass_perm_host(ppo_xp *h, uint32_t *out, size_t n);
+/* Per-minibatch (mean, unbiased std) of the current pass, K pairs of f32 to the host
+ * (synchronises).  correct_std: data.rs:196-200. */
+int ppo_xp_pass_stats_host(ppo_xp *h, float *mean_std_out, size_t k);
+
+/* ---- env-sharded multi-GPU (no counterpart in the reference, which is single device) --- */
+
+/* Per-minibatch advantage sums cross ranks.  mode 0: none (single GPU).  mode 2 "external":
+ * ppo_xp_pass_begin() stops after writing this rank's K triples (count, sum, sum of squares;
+ * f64) to ppo_xp_pass_sums_device(); the caller all-reduces (sum) that buffer over the ranks
+ * on the handle's stream and then calls ppo_xp_pass_finish().  mode 1 "rccl": the library
+ * itself calls ncclAllReduce on `nccl_comm` (a ncclComm_t created by the caller) between
+ * the two halves. */
+int ppo_xp_set_exchange(ppo_xp *h, int mode, void *nccl_comm);
+double *ppo_xp_pass_sums_device(ppo_xp *h); /* [K][3] f64 */
+int ppo_xp_pass_finish(ppo_xp *h);
+/* RCCL bootstrap helpers for mode 1 (thin wrappers over ncclGetUniqueId / ncclCommInitRank /
+ * ncclCommDestroy so that a host without RCCL bindings can still build the communicator). */
+int ppo_xp_rccl_unique_id(void *out128);
+int ppo_xp_rccl_comm_init(void **comm_out, const void *unique_id128, int rank, int world);
+int ppo_xp_rccl_comm_destroy(void *comm);
+
+/* ---- plumbing --------------------------------------------------------------------------- */
+
+void *ppo_xp_stream(const ppo_xp *h);            /* hipStream_t of the handle                */
+int ppo_xp_set_stream(ppo_xp *h, void *stream);  /* borrow a caller-owned stream instead     */
+int ppo_xp_sync(ppo_xp *h);                      /* hipStreamSynchronize                     */
+int ppo_xp_device(const ppo_xp *h);
+
+/* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline numbers).
+ * enable != 0 starts recording an event pair around every kernel launch; collect
+ * synchronises, adds up elapsed ms and launch counts per kernel id and resets. */
+enum { PPO_XP_K_GAE = 0, PPO_XP_K_GAE_SUMMARY, PPO_XP_K_GAE_CARRY, PPO_XP_K_PACK, PPO_XP_K_GATHER,
+       PPO_XP_K_FINALIZE, PPO_XP_K_NORMALIZE, PPO_XP_K_COUNT };
+int ppo_xp_prof_enable(ppo_xp *h, int enable);
+int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launches_out /*[K_COUNT]*/);
+const char *ppo_xp_kernel_name(int kernel_id);
+
+/* Tunables (A/B measurements in one process): "gather_nt" 0/1, "gather_unroll" 1/2/4/8,
+ * "gae_unroll" ... Unknown names => PPO_XP_EINVAL. */
+int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
+
+const char *ppo_xp_last_error(void);
+const char *ppo_xp_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPO_XP_H */

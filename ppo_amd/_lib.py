@@ -1,0 +1,116 @@
+"""ctypes binding of libppo_xp.so (include/ppo_xp.h).
+
+The library is HIP only.  If it is missing, or no GPU is usable, calls fail loudly with
+PpoXpError: there is no CPU fallback in this package.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libppo_xp.so")
+
+OK, EINVAL, ENOMEM, EIO, ENODEV, ESTATE = 0, -22, -12, -5, -19, -1
+GAE_SEQUENTIAL, GAE_ASSOC, GAE_NO_PACK = 0, 1, 0x100
+K_NAMES = ("gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records", "gather", "finalize_stats", "normalize")
+K_GAE, K_GAE_SUMMARY, K_GAE_CARRY, K_PACK, K_GATHER, K_FINALIZE, K_NORMALIZE = range(7)
+K_COUNT = 7
+
+
+def gae_chunk(length: int) -> int:
+    return (int(length) & 0xFFFF) << 16
+
+
+class PpoXpError(RuntimeError):
+    """A C-ABI call failed.  `.code` is the PPO_XP_E* value."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"ppo_xp error {code}: {msg}")
+        self.code = code
+
+
+class PpoXpPanic(PpoXpError, AssertionError):
+    """PPO_XP_EINVAL: the reference would have panicked (assert_eq! on sizes)."""
+
+
+class ViewsT(C.Structure):
+    _fields_ = [("num_steps", C.c_size_t), ("obs_size", C.c_size_t), ("observations", C.c_void_p),
+                ("actions", C.c_void_p), ("values", C.c_void_p), ("neglogps", C.c_void_p),
+                ("rewards", C.c_void_p), ("dones", C.c_void_p), ("returns", C.c_void_p),
+                ("advantages", C.c_void_p)]
+
+
+class BatchView(C.Structure):
+    _fields_ = [("index", C.c_size_t), ("batch_size", C.c_size_t), ("obs_size", C.c_size_t),
+                ("observations", C.c_void_p), ("actions", C.c_void_p), ("values", C.c_void_p),
+                ("neglogps", C.c_void_p), ("returns", C.c_void_p), ("advantages", C.c_void_p),
+                ("adv_mean", C.c_float), ("adv_std", C.c_float)]
+
+
+# name -> (restype, argtypes); every symbol include/ppo_xp.h declares.
+_vp, _sz, _i, _f, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_uint64
+SYMBOLS = {
+    "ppo_xp_create": (_i, [C.POINTER(_vp), _i, _sz, _sz, _sz, _f, _f]),
+    "ppo_xp_destroy": (None, [_vp]),
+    "ppo_xp_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "ppo_xp_add_many": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _sz]),
+    "ppo_xp_add_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "ppo_xp_reset_counter": (None, [_vp]),
+    "ppo_xp_len": (_sz, [_vp]),
+    "ppo_xp_counter": (_sz, [_vp]),
+    "ppo_xp_last_values_idx": (_sz, [_vp]),
+    "ppo_xp_returns": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ppo_xp_views": (_i, [_vp, C.POINTER(ViewsT)]),
+    "ppo_xp_pass_begin": (_i, [_vp, _sz, _vp, _u64]),
+    "ppo_xp_pass_begin_device": (_i, [_vp, _sz, _vp]),
+    "ppo_xp_pass_next": (_i, [_vp, C.POINTER(BatchView)]),
+    "ppo_xp_pass_num_batches": (_sz, [_vp]),
+    "ppo_xp_pass_perm_device": (_vp, [_vp]),
+    "ppo_xp_pass_perm_host": (_i, [_vp, _vp, _sz]),
+    "ppo_xp_pass_stats_host": (_i, [_vp, _vp, _sz]),
+    "ppo_xp_set_exchange": (_i, [_vp, _i, _vp]),
+    "ppo_xp_pass_sums_device": (_vp, [_vp]),
+    "ppo_xp_pass_finish": (_i, [_vp]),
+    "ppo_xp_rccl_unique_id": (_i, [_vp]),
+    "ppo_xp_rccl_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "ppo_xp_rccl_comm_destroy": (_i, [_vp]),
+    "ppo_xp_stream": (_vp, [_vp]),
+    "ppo_xp_set_stream": (_i, [_vp, _vp]),
+    "ppo_xp_sync": (_i, [_vp]),
+    "ppo_xp_device": (_i, [_vp]),
+    "ppo_xp_prof_enable": (_i, [_vp, _i]),
+    "ppo_xp_prof_collect": (_i, [_vp, _vp, _vp]),
+    "ppo_xp_kernel_name": (C.c_char_p, [_i]),
+    "ppo_xp_set_tunable": (_i, [_vp, C.c_char_p, C.c_long]),
+    "ppo_xp_last_error": (C.c_char_p, []),
+    "ppo_xp_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libppo_xp.so and type every entry point.  Raises if the library is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PpoXpError(ENODEV, f"{LIB_PATH} is not built (run `make -C ppo_amd/csrc`); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return (load().ppo_xp_last_error() or b"").decode()
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        msg = last_error()
+        raise (PpoXpPanic if rc == EINVAL else PpoXpError)(rc, msg)
+    return rc

@@ -1,0 +1,241 @@
+// GAE(lambda) / returns kernels for gfx950 (MI355X).  HBM-bound scans: no MFMA.
+//
+// Replaces ExperienceBuffer::returns (ppo/src/common/buffer.rs:187-225) fused with
+// `advantages = returns - values` of ExperienceBatcher::new (ppo/src/model/data.rs:62).
+//
+// Layout: every scalar stream is [T, N] row-major (env index fastest), exactly the reference's
+// Array2 layout (buffer.rs:32-36), so one wave64 = 64 consecutive envs reads 256 contiguous
+// bytes per stream per time step.  Time runs in registers.
+//
+// Arithmetic: fp32, every operation rounded on its own, evaluation order of buffer.rs:217-222.
+// This translation unit is compiled with -ffp-contract=off so that no FMA is formed.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ppoxp {
+
+// Packed per-transition record read by the gather kernel: ONE 32-byte sector per gathered row
+// instead of four scattered 4/8-byte reads (values, neglogps, returns, actions).
+struct __attribute__((aligned(32))) Rec {
+  float v, nlp, ret, adv;  // value, neglogp, fl(A+v), fl(fl(A+v)-v)
+  int64_t act;             // usize in the reference (buffer.rs:33)
+  int64_t pad;
+};
+static_assert(sizeof(Rec) == 32, "Rec must be one 32-byte sector");
+
+struct GaeArgs {
+  const float *rewards, *values, *dones, *neglogps;  // [T, N]
+  const int64_t *actions;                            // [T, N]
+  const uint8_t *last_dones;                         // [N] Rust bools
+  float *returns, *adv;                              // [T*N]
+  Rec *rec;                                          // [T*N]
+  const float *carry;                                // [C, N] chunk carry-in (assoc) or nullptr
+  float *sumP, *sumQ;                                // [C, N] chunk summaries (assoc)
+  unsigned N, len, lvi, chunk;                       // chunk = time steps per blockIdx.y
+  float gamma, gl;                                   // gl = fl(gamma*lambda)  (buffer.rs:219)
+};
+
+// One time step of buffer.rs:217-222, in the reference's rounding order.
+__device__ __forceinline__ void gae_step(float r, float v, float v_next, float nnt_next, float gamma,
+                                         float gl, float &A, float &ret, float &adv) {
+  float x1 = v_next * nnt_next;
+  float x2 = x1 * gamma;
+  float x3 = r + x2;
+  float delta = x3 - v;       // (rewards + nextvalues*nextnonterminal*gamma) - values
+  float y1 = nnt_next * A;
+  float y2 = y1 * gl;
+  A = delta + y2;             // lastgaelam = delta + nextnonterminal*lastgaelam*(gamma*lambda)
+  ret = A + v;                // buffer.rs:222
+  adv = ret - v;              // data.rs:62
+}
+
+// K1 (and the fix-up phase of K2): sequential reverse-time scan, one lane per env.
+// grid = (ceil(N/64), C), block = 64.  blockIdx.y = time chunk (C = 1 for the pure sequential
+// algorithm).  Loads of the next U time steps are issued before the current U are consumed.
+template <bool PACK, int U>
+__global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
+  const unsigned e = blockIdx.x * 64u + threadIdx.x;
+  if (e >= a.N) return;
+  const unsigned c = blockIdx.y;
+  const int t_lo = (int)(c * a.chunk);
+  int t_hi = (int)min((c + 1) * a.chunk, a.len) - 1;
+  if (t_hi < t_lo) return;
+  const size_t N = a.N;
+
+  float v_next, nnt_next, A;
+  if ((unsigned)t_hi == a.len - 1) {           // buffer.rs:209-210, 201-204
+    v_next = a.values[(size_t)a.lvi * N + e];
+    nnt_next = a.last_dones[e] ? 0.0f : 1.0f;
+    A = 0.0f;                                  // buffer.rs:196
+  } else {                                     // buffer.rs:212-213, 199
+    v_next = a.values[(size_t)(t_hi + 1) * N + e];
+    nnt_next = 1.0f - a.dones[(size_t)(t_hi + 1) * N + e];
+    A = a.carry[(size_t)c * N + e];
+  }
+
+  float r[U], v[U], d[U], nl[U];
+  int64_t ac[U];
+  auto load = [&](int t_top) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = max(t_top - u, t_lo);            // clamped: tail re-reads row t_lo (cached)
+      size_t i = (size_t)t * N + e;
+      r[u] = a.rewards[i];
+      v[u] = a.values[i];
+      d[u] = a.dones[i];
+      if (PACK) { nl[u] = a.neglogps[i]; ac[u] = a.actions[i]; }
+    }
+  };
+
+  load(t_hi);
+  for (int t_top = t_hi; t_top >= t_lo; t_top -= U) {
+    float rc[U], vc[U], dc[U], nlc[U];
+    int64_t acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { rc[u] = r[u]; vc[u] = v[u]; dc[u] = d[u]; if (PACK) { nlc[u] = nl[u]; acc[u] = ac[u]; } }
+    if (t_top - U >= t_lo) load(t_top - U);    // prefetch the next U steps (wave-uniform)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = t_top - u;
+      if (t >= t_lo) {
+        float ret, adv;
+        gae_step(rc[u], vc[u], v_next, nnt_next, a.gamma, a.gl, A, ret, adv);
+        size_t i = (size_t)t * N + e;
+        a.returns[i] = ret;
+        a.adv[i] = adv;
+        if (PACK) {
+          float4 lo = make_float4(vc[u], nlc[u], ret, adv);
+          longlong2 hi; hi.x = acc[u]; hi.y = 0;
+          float4 *dst = reinterpret_cast<float4 *>(a.rec + i);
+          dst[0] = lo;
+          *reinterpret_cast<longlong2 *>(dst + 1) = hi;
+        }
+        v_next = vc[u];
+        nnt_next = 1.0f - dc[u];
+      }
+    }
+  }
+}
+
+// K2 phase 1: per (chunk c >= 1, env) summary of the chunk's affine map  A_in -> A_out:
+//   A_{t} = delta_t + a_t * A_{t+1},  a_t = fl(nnt_{t+1} * gl)
+// composed over the chunk:  A_{t_lo} = Q + P * A_{t_hi+1}.  Q is computed with exactly the
+// sequential kernel's operations (carry-in 0); P is the running product of the a_t.
+// grid = (ceil(N/64), C-1): chunk index = blockIdx.y + 1 (chunk 0 feeds nobody).
+template <int U>
+__global__ __launch_bounds__(64) void gae_chunk_summary_kernel(GaeArgs a) {
+  const unsigned e = blockIdx.x * 64u + threadIdx.x;
+  if (e >= a.N) return;
+  const unsigned c = blockIdx.y + 1;
+  const int t_lo = (int)(c * a.chunk);
+  int t_hi = (int)min((c + 1) * a.chunk, a.len) - 1;
+  if (t_hi < t_lo) return;
+  const size_t N = a.N;
+  float v_next, nnt_next;
+  if ((unsigned)t_hi == a.len - 1) {
+    v_next = a.values[(size_t)a.lvi * N + e];
+    nnt_next = a.last_dones[e] ? 0.0f : 1.0f;
+  } else {
+    v_next = a.values[(size_t)(t_hi + 1) * N + e];
+    nnt_next = 1.0f - a.dones[(size_t)(t_hi + 1) * N + e];
+  }
+  float P = 1.0f, Q = 0.0f;
+  for (int t_top = t_hi; t_top >= t_lo; t_top -= U) {
+    float r[U], v[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = max(t_top - u, t_lo);
+      size_t i = (size_t)t * N + e;
+      r[u] = a.rewards[i]; v[u] = a.values[i]; d[u] = a.dones[i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t_top - u >= t_lo) {
+        float ret, adv;
+        P = P * (nnt_next * a.gl);
+        gae_step(r[u], v[u], v_next, nnt_next, a.gamma, a.gl, Q, ret, adv);
+        v_next = v[u];
+        nnt_next = 1.0f - d[u];
+      }
+    }
+  }
+  a.sumP[(size_t)c * N + e] = P;
+  a.sumQ[(size_t)c * N + e] = Q;
+}
+
+// K2 phase 2: LDS-staged associative scan over the chunk summaries.
+// carry[c] = A entering chunk c from the future:  carry[C-1] = 0,
+//            carry[c] = Q[c+1] + P[c+1] * carry[c+1].
+// One workgroup = 64 envs x W waves.  The C-1 maps are cut into W consecutive segments; each
+// wave composes its segment (registers), the W segment maps are combined by a Hillis-Steele
+// scan in LDS with the associative operator
+//     (P_l, Q_l) o (P_e, Q_e) = (P_l * P_e, Q_l + P_l * Q_e)      (l applied after e)
+// and each wave then replays its segment from its carry-in.  grid = ceil(N/64), block = 64*W.
+template <int W>
+__global__ __launch_bounds__(64 * W) void gae_carry_scan_kernel(const float *__restrict__ sumP,
+                                                                const float *__restrict__ sumQ,
+                                                                float *__restrict__ carry, unsigned N,
+                                                                unsigned C) {
+  __shared__ float sP[2][W][64];
+  __shared__ float sQ[2][W][64];
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const unsigned e = blockIdx.x * 64u + lane;
+  const bool live = e < N;
+  // processing order j = 0 .. J-1 applies the map of chunk c = C-1-j;  Y_0 = 0, Y_{j+1} = f_j(Y_j),
+  // carry[C-1-j] = Y_j.
+  const unsigned J = C - 1;
+  const unsigned S = (J + W - 1) / W;
+  const unsigned j0 = min(w * S, J), j1 = min(j0 + S, J);
+  float P = 1.0f, Q = 0.0f;
+  if (live) {
+    for (unsigned j = j0; j < j1; ++j) {
+      size_t i = (size_t)(C - 1 - j) * N + e;
+      float p = sumP[i], q = sumQ[i];
+      Q = q + p * Q;
+      P = p * P;
+    }
+  }
+  int cur = 0;
+  sP[0][w][lane] = P; sQ[0][w][lane] = Q;
+  __syncthreads();
+#pragma unroll
+  for (unsigned off = 1; off < (unsigned)W; off <<= 1) {
+    float p = sP[cur][w][lane], q = sQ[cur][w][lane];
+    if (w >= off) {
+      float pe = sP[cur][w - off][lane], qe = sQ[cur][w - off][lane];
+      q = q + p * qe;
+      p = p * pe;
+    }
+    sP[cur ^ 1][w][lane] = p; sQ[cur ^ 1][w][lane] = q;
+    cur ^= 1;
+    __syncthreads();
+  }
+  if (!live) return;
+  float Y = (w == 0) ? 0.0f : sQ[cur][w - 1][lane];  // inclusive prefix of earlier segments applied to 0
+  if (w == 0) carry[(size_t)(C - 1) * N + e] = 0.0f;
+  for (unsigned j = j0; j < j1; ++j) {
+    size_t i = (size_t)(C - 1 - j) * N + e;
+    Y = sumQ[i] + sumP[i] * Y;
+    carry[(size_t)(C - 2 - j) * N + e] = Y;
+  }
+}
+
+// Builds the packed records from the flat streams (only needed after a PPO_XP_GAE_NO_PACK
+// returns()).
+__global__ __launch_bounds__(256) void pack_records_kernel(const float *__restrict__ values,
+                                                           const float *__restrict__ neglogps,
+                                                           const float *__restrict__ returns,
+                                                           const float *__restrict__ adv,
+                                                           const int64_t *__restrict__ actions,
+                                                           Rec *__restrict__ rec, size_t M) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
+    float4 lo = make_float4(values[i], neglogps[i], returns[i], adv[i]);
+    longlong2 hi; hi.x = actions[i]; hi.y = 0;
+    float4 *dst = reinterpret_cast<float4 *>(rec + i);
+    dst[0] = lo;
+    *reinterpret_cast<longlong2 *>(dst + 1) = hi;
+  }
+}
+
+}  // namespace ppoxp

@@ -1,0 +1,719 @@
+// libppo_xp.so — C ABI (include/ppo_xp.h) over the HIP kernels of the experience path.
+// gfx950 only; there is no CPU fallback anywhere in this file.
+//
+// Host-side state mirrors struct ExperienceBuffer (ppo/src/common/buffer.rs:23-39) and
+// ExperienceBatcher / ExperienceBatcherIterator (ppo/src/model/data.rs:14-19,105-109).
+#include "../../include/ppo_xp.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels_gae.h"
+#include "kernels_gather.h"
+#include "shuffle.h"
+
+using namespace ppoxp;
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+
+static int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return fail(_e == hipErrorOutOfMemory ? PPO_XP_ENOMEM : PPO_XP_EIO, "%s failed: %s (%s:%d)", \
+                  #expr, hipGetErrorString(_e), __FILE__, __LINE__);                           \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------
+// RCCL, bound lazily (the library has no link-time dependency on librccl)
+// ---------------------------------------------------------------------------------------
+namespace {
+struct RcclUniqueId { char internal[128]; };
+struct RcclApi {
+  void *lib = nullptr;
+  int (*GetUniqueId)(RcclUniqueId *) = nullptr;
+  int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
+  int (*CommDestroy)(void *) = nullptr;
+  int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+
+int rccl_load() {
+  if (g_rccl.lib) return 0;
+  const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void *lib = nullptr;
+  for (const char *n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+  if (!lib) return fail(PPO_XP_EIO, "dlopen(librccl) failed: %s", dlerror());
+  RcclApi a;
+  a.lib = lib;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
+    return fail(PPO_XP_EIO, "librccl lacks an expected ncclXxx symbol");
+  g_rccl = a;
+  return 0;
+}
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclSum = 0
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// handle
+// ---------------------------------------------------------------------------------------
+struct ProfRec { int kid; hipEvent_t a, b; };
+
+struct ppo_xp {
+  int device = 0;
+  size_t capacity = 0, N = 0, D = 0;
+  float gamma = 0.99f, lambda = 0.95f;
+  // ring state — buffer.rs:24-25,38
+  size_t counter = 0, last_values_idx = 0;
+  // device streams — buffer.rs:31-36
+  float *obs = nullptr, *rewards = nullptr, *values = nullptr, *dones = nullptr, *neglogps = nullptr;
+  int64_t *actions = nullptr;
+  // GAE outputs
+  float *returns = nullptr, *adv = nullptr;
+  Rec *rec = nullptr;
+  uint8_t *last_dones_dev = nullptr, *last_dones_pin = nullptr;  // pin: kPinSlots x N bytes
+  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool pin_used[4] = {false, false, false, false};
+  unsigned pin_next = 0;
+  float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
+  size_t scan_cap = 0;       // elements allocated in carry/sumP/sumQ
+  bool have_returns = false, have_rec = false;
+  size_t ret_len = 0;        // len at the time of returns()
+  // pass state — data.rs:105-109
+  uint32_t *perm = nullptr;  // [capacity*N] owned copy (host-drawn permutations)
+  const uint32_t *perm_cur = nullptr;  // permutation of the current pass: perm, or a borrowed device array
+  float *obs_out = nullptr, *val_out = nullptr, *nlp_out = nullptr, *ret_out = nullptr, *adv_out = nullptr;
+  int64_t *act_out = nullptr;
+  size_t slab_rows = 0;
+  double2 *partials = nullptr; size_t partials_cap = 0;
+  double *sums = nullptr; float *stats = nullptr; size_t sums_cap = 0;
+  size_t pass_B = 0, pass_K = 0, pass_M = 0, pass_iter = 0;
+  bool pass_active = false, pass_pending_finish = false;
+  std::vector<uint32_t> perm_host;
+  // exchange
+  int xmode = 0; void *comm = nullptr;
+  // stream / profiling
+  hipStream_t stream = nullptr; bool own_stream = false;
+  bool prof = false;
+  std::vector<ProfRec> prof_recs;
+  std::vector<hipEvent_t> ev_pool;
+  // tunables
+  long gather_nt = 1, gather_unroll = 8, gae_unroll = 8, carry_waves = 16;
+};
+
+namespace {
+
+size_t buf_len(const ppo_xp *h) { return h->counter >= h->capacity ? h->capacity : h->counter; }  // buffer.rs:123-129
+
+struct ProfScope {
+  ppo_xp *h; int kid; hipEvent_t a = nullptr, b = nullptr;
+  ProfScope(ppo_xp *h_, int kid_) : h(h_), kid(kid_) {
+    if (!h->prof) return;
+    a = take(); b = take();
+    if (a && b) (void)hipEventRecord(a, h->stream);
+  }
+  ~ProfScope() {
+    if (!h->prof || !a || !b) return;
+    (void)hipEventRecord(b, h->stream);
+    h->prof_recs.push_back({kid, a, b});
+  }
+  hipEvent_t take() {
+    if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+  }
+};
+
+template <typename T>
+int dev_alloc(T **p, size_t count, bool zero) {
+  *p = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  HIP_TRY(hipMalloc((void **)p, bytes));
+  if (zero) HIP_TRY(hipMemset(*p, 0, bytes));
+  return 0;
+}
+
+template <typename T>
+void dev_free(T *&p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+int launch_check(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(PPO_XP_EIO, "launch of %s failed: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+// ---- GAE launches --------------------------------------------------------------------------
+template <bool PACK>
+int launch_gae_scan(ppo_xp *h, const GaeArgs &a, unsigned chunks) {
+  dim3 grid((unsigned)((h->N + 63) / 64), chunks), block(64);
+  ProfScope ps(h, PPO_XP_K_GAE);
+  switch (h->gae_unroll) {
+    case 4: hipLaunchKernelGGL((gae_scan_kernel<PACK, 4>), grid, block, 0, h->stream, a); break;
+    case 16: hipLaunchKernelGGL((gae_scan_kernel<PACK, 16>), grid, block, 0, h->stream, a); break;
+    default: hipLaunchKernelGGL((gae_scan_kernel<PACK, 8>), grid, block, 0, h->stream, a); break;
+  }
+  return launch_check("gae_scan_kernel");
+}
+
+int run_gae(ppo_xp *h, int algo) {
+  const size_t len = buf_len(h);
+  const size_t N = h->N;
+  if (len == 0 || N == 0) return 0;
+  const bool pack = !(algo & PPO_XP_GAE_NO_PACK);
+  const int kind = algo & 0xff;
+  GaeArgs a{};
+  a.rewards = h->rewards; a.values = h->values; a.dones = h->dones; a.neglogps = h->neglogps;
+  a.actions = h->actions; a.last_dones = h->last_dones_dev; a.returns = h->returns; a.adv = h->adv;
+  a.rec = h->rec; a.N = (unsigned)N; a.len = (unsigned)len; a.lvi = (unsigned)h->last_values_idx;
+  a.gamma = h->gamma;
+  a.gl = h->gamma * h->lambda;  // one fp32 product, computed first (buffer.rs:219)
+  unsigned chunks = 1;
+  a.chunk = (unsigned)len;
+  if (kind == PPO_XP_GAE_ASSOC) {
+    unsigned L = ((unsigned)algo >> 16) & 0xffffu;
+    const unsigned groups = (unsigned)((N + 63) / 64);
+    if (L == 0) {
+      // enough (chunk, env-group) waves to fill 256 CUs several times over, chunks >= 32 steps
+      unsigned want = std::max(1u, 4096u / groups);
+      unsigned c = (unsigned)std::min<size_t>(want, (len + 31) / 32);
+      c = std::max(c, 1u);
+      L = (unsigned)((len + c - 1) / c);
+    }
+    L = std::max(1u, std::min<unsigned>(L, (unsigned)len));
+    chunks = (unsigned)((len + L - 1) / L);
+    if (chunks > 65535u) { L = (unsigned)((len + 65534) / 65535); chunks = (unsigned)((len + L - 1) / L); }
+    a.chunk = L;
+  }
+  if (chunks > 1) {
+    const size_t need = (size_t)chunks * N;
+    if (need > h->scan_cap) {
+      dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ); h->scan_cap = 0;
+      if (int rc = dev_alloc(&h->carry, need, false)) return rc;
+      if (int rc = dev_alloc(&h->sumP, need, false)) return rc;
+      if (int rc = dev_alloc(&h->sumQ, need, false)) return rc;
+      h->scan_cap = need;
+    }
+    a.carry = h->carry; a.sumP = h->sumP; a.sumQ = h->sumQ;
+    {
+      dim3 grid((unsigned)((N + 63) / 64), chunks - 1), block(64);
+      ProfScope ps(h, PPO_XP_K_GAE_SUMMARY);
+      hipLaunchKernelGGL((gae_chunk_summary_kernel<8>), grid, block, 0, h->stream, a);
+      if (int rc = launch_check("gae_chunk_summary_kernel")) return rc;
+    }
+    {
+      dim3 grid((unsigned)((N + 63) / 64));
+      ProfScope ps(h, PPO_XP_K_GAE_CARRY);
+      if (h->carry_waves == 4)
+        hipLaunchKernelGGL((gae_carry_scan_kernel<4>), grid, dim3(256), 0, h->stream, h->sumP, h->sumQ, h->carry, (unsigned)N, chunks);
+      else if (h->carry_waves == 8)
+        hipLaunchKernelGGL((gae_carry_scan_kernel<8>), grid, dim3(512), 0, h->stream, h->sumP, h->sumQ, h->carry, (unsigned)N, chunks);
+      else
+        hipLaunchKernelGGL((gae_carry_scan_kernel<16>), grid, dim3(1024), 0, h->stream, h->sumP, h->sumQ, h->carry, (unsigned)N, chunks);
+      if (int rc = launch_check("gae_carry_scan_kernel")) return rc;
+    }
+  }
+  int rc = pack ? launch_gae_scan<true>(h, a, chunks) : launch_gae_scan<false>(h, a, chunks);
+  if (rc) return rc;
+  h->have_returns = true;
+  h->have_rec = pack;
+  h->ret_len = len;
+  return 0;
+}
+
+// ---- gather launch -------------------------------------------------------------------------
+template <int V, int U, bool NT>
+void launch_gather_v(ppo_xp *h, const GatherArgs &g, unsigned blocks, bool pow2) {
+  if (pow2) hipLaunchKernelGGL((gather_kernel<V, U, NT, true>), dim3(blocks), dim3(256), 0, h->stream, g);
+  else hipLaunchKernelGGL((gather_kernel<V, U, NT, false>), dim3(blocks), dim3(256), 0, h->stream, g);
+}
+
+int launch_gather(ppo_xp *h, GatherArgs g, unsigned blocks) {
+  const unsigned D = (unsigned)h->D;
+  const int V = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+  g.D = D; g.Q = D / V;
+  const bool pow2 = g.Q != 0 && (g.Q & (g.Q - 1)) == 0;
+  g.qshift = 0;
+  if (pow2) while ((1u << g.qshift) < g.Q) ++g.qshift;
+  ProfScope ps(h, PPO_XP_K_GATHER);
+  if (V == 4) {
+    const bool nt = h->gather_nt != 0;
+    switch (h->gather_unroll) {
+      case 4: nt ? launch_gather_v<4, 4, true>(h, g, blocks, pow2) : launch_gather_v<4, 4, false>(h, g, blocks, pow2); break;
+      case 16: nt ? launch_gather_v<4, 16, true>(h, g, blocks, pow2) : launch_gather_v<4, 16, false>(h, g, blocks, pow2); break;
+      default: nt ? launch_gather_v<4, 8, true>(h, g, blocks, pow2) : launch_gather_v<4, 8, false>(h, g, blocks, pow2); break;
+    }
+  } else if (V == 2) {
+    launch_gather_v<2, 8, false>(h, g, blocks, pow2);
+  } else {
+    launch_gather_v<1, 8, false>(h, g, blocks, pow2);
+  }
+  return launch_check("gather_kernel");
+}
+
+int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
+  const size_t rows = K * B;
+  if (rows > h->slab_rows) {
+    dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out);
+    dev_free(h->ret_out); dev_free(h->adv_out); h->slab_rows = 0;
+    if (int rc = dev_alloc(&h->obs_out, rows * h->D, false)) return rc;
+    if (int rc = dev_alloc(&h->act_out, rows, false)) return rc;
+    if (int rc = dev_alloc(&h->val_out, rows, false)) return rc;
+    if (int rc = dev_alloc(&h->nlp_out, rows, false)) return rc;
+    if (int rc = dev_alloc(&h->ret_out, rows, false)) return rc;
+    if (int rc = dev_alloc(&h->adv_out, rows, false)) return rc;
+    h->slab_rows = rows;
+  }
+  const size_t tiles = K * ((B + 255) / 256);
+  if (tiles > h->partials_cap) {
+    dev_free(h->partials); h->partials_cap = 0;
+    if (int rc = dev_alloc(&h->partials, tiles, false)) return rc;
+    h->partials_cap = tiles;
+  }
+  if (K > h->sums_cap) {
+    dev_free(h->sums); dev_free(h->stats); h->sums_cap = 0;
+    if (int rc = dev_alloc(&h->sums, 3 * K, true)) return rc;
+    if (int rc = dev_alloc(&h->stats, 2 * K, true)) return rc;
+    h->sums_cap = K;
+  }
+  return 0;
+}
+
+int pass_finish_impl(ppo_xp *h) {
+  const size_t K = h->pass_K, B = h->pass_B;
+  if (K == 0) { h->pass_pending_finish = false; return 0; }
+  unsigned bx = (unsigned)std::min<size_t>((B + 1023) / 1024, 4096);
+  bx = std::max(bx, 1u);
+  ProfScope ps(h, PPO_XP_K_NORMALIZE);
+  hipLaunchKernelGGL(normalize_kernel, dim3(bx, (unsigned)K), dim3(256), 0, h->stream, h->adv_out, h->sums,
+                     h->stats, B);
+  h->pass_pending_finish = false;
+  return launch_check("normalize_kernel");
+}
+
+// perm already in h->perm (device).
+int pass_begin_impl(ppo_xp *h, size_t B) {
+  const size_t len = buf_len(h), M = len * h->N;
+  if (!h->have_returns || h->ret_len != len)
+    return fail(PPO_XP_ESTATE, "pass_begin: call ppo_xp_returns() first (ExperienceBatcher::new takes the returns, data.rs:27)");
+  h->pass_B = B; h->pass_M = M; h->pass_iter = 0; h->pass_active = true; h->pass_pending_finish = false;
+  h->pass_K = (B > M) ? 0 : (M + B - 1) / B;                 // data.rs:117-126
+  const size_t K = h->pass_K;
+  if (K == 0) return 0;
+  if (K * ((B + 255) / 256) > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
+  if (int rc = ensure_pass_buffers(h, K, B)) return rc;
+  if (!h->have_rec) {
+    ProfScope ps(h, PPO_XP_K_PACK);
+    unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, 8192);
+    hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, h->stream, h->values, h->neglogps,
+                       h->returns, h->adv, h->actions, h->rec, M);
+    if (int rc = launch_check("pack_records_kernel")) return rc;
+    h->have_rec = true;
+  }
+  GatherArgs g{};
+  g.obs = h->obs; g.rec = h->rec; g.perm = h->perm_cur; g.obs_out = h->obs_out; g.act_out = h->act_out;
+  g.val_out = h->val_out; g.nlp_out = h->nlp_out; g.ret_out = h->ret_out; g.adv_out = h->adv_out;
+  g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256);
+  const unsigned blocks = (unsigned)(K * g.tiles_per_mb);
+  if (int rc = launch_gather(h, g, blocks)) return rc;
+  {
+    ProfScope ps(h, PPO_XP_K_FINALIZE);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
+                       g.tiles_per_mb, B);
+    if (int rc = launch_check("finalize_stats_kernel")) return rc;
+  }
+  if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
+  if (h->xmode == 1) {
+    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+  }
+  return pass_finish_impl(h);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char *ppo_xp_last_error(void) { return g_err.c_str(); }
+const char *ppo_xp_version(void) { return "ppo_xp 0.1 (gfx950)"; }
+
+const char *ppo_xp_kernel_name(int k) {
+  static const char *names[PPO_XP_K_COUNT] = {"gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records",
+                                              "gather", "finalize_stats", "normalize"};
+  return (k >= 0 && k < PPO_XP_K_COUNT) ? names[k] : "?";
+}
+
+int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, size_t obs_size, float gamma,
+                  float lambda) {
+  if (!out) return fail(PPO_XP_EINVAL, "create: out is NULL");
+  *out = nullptr;
+  if (capacity == 0 || num_envs == 0 || obs_size == 0)
+    return fail(PPO_XP_EINVAL, "create: capacity, num_envs and obs_size must be > 0");
+  if (capacity * num_envs > 0xFFFFFFFFull)
+    return fail(PPO_XP_EINVAL, "create: capacity*num_envs must be < 2^32 (u32 permutation indices)");
+  if (num_envs > 0x7FFFFFFFull || obs_size > 0x00FFFFFFull || capacity > 0x7FFFFFFFull)
+    return fail(PPO_XP_EINVAL, "create: dimension too large");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(PPO_XP_ENODEV, "create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(PPO_XP_ENODEV, "create: device %d of %d", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  ppo_xp *h = new (std::nothrow) ppo_xp();
+  if (!h) return fail(PPO_XP_ENOMEM, "create: host allocation failed");
+  h->device = device; h->capacity = capacity; h->N = num_envs; h->D = obs_size;
+  h->gamma = gamma; h->lambda = lambda;
+  const size_t cn = capacity * num_envs;
+  int rc = 0;
+  // Array::zeros — buffer.rs:60-65
+  if (!rc) rc = dev_alloc(&h->obs, cn * obs_size, true);
+  if (!rc) rc = dev_alloc(&h->rewards, cn, true);
+  if (!rc) rc = dev_alloc(&h->actions, cn, true);
+  if (!rc) rc = dev_alloc(&h->values, cn, true);
+  if (!rc) rc = dev_alloc(&h->dones, cn, true);
+  if (!rc) rc = dev_alloc(&h->neglogps, cn, true);
+  if (!rc) rc = dev_alloc(&h->returns, cn, true);
+  if (!rc) rc = dev_alloc(&h->adv, cn, true);
+  if (!rc) rc = dev_alloc(&h->rec, cn, true);
+  if (!rc) rc = dev_alloc(&h->perm, cn, true);
+  if (!rc) rc = dev_alloc(&h->last_dones_dev, num_envs, true);
+  if (!rc && hipHostMalloc((void **)&h->last_dones_pin, 4 * std::max<size_t>(num_envs, 1), hipHostMallocDefault) != hipSuccess)
+    rc = fail(PPO_XP_ENOMEM, "create: hipHostMalloc failed");
+  if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+    rc = fail(PPO_XP_EIO, "create: hipStreamCreate failed");
+  if (!rc) h->own_stream = true;
+  for (int i = 0; i < 4 && !rc; ++i)
+    if (hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
+  if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(PPO_XP_EIO, "create: device sync failed");
+  if (rc) { ppo_xp_destroy(h); return rc; }
+  *out = h;
+  return 0;
+}
+
+void ppo_xp_destroy(ppo_xp *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
+  dev_free(h->obs); dev_free(h->rewards); dev_free(h->actions); dev_free(h->values); dev_free(h->dones);
+  dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->perm);
+  dev_free(h->last_dones_dev); dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
+  dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out);
+  dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
+  if (h->last_dones_pin) (void)hipHostFree(h->last_dones_pin);
+  if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static void advance_counter(ppo_xp *h, size_t idx) {
+  h->last_values_idx = idx;                                     // buffer.rs:115
+  h->counter += 1;                                              // buffer.rs:117
+  if (h->counter >= h->capacity) h->counter = (h->counter % h->capacity) + h->capacity;  // buffer.rs:118-120
+  h->have_returns = false; h->have_rec = false; h->pass_active = false;
+}
+
+int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions, const float *vals,
+                    const uint8_t *dones, const float *neglogps, size_t n, size_t steps) {
+  if (!h) return fail(PPO_XP_EINVAL, "add: handle is NULL");
+  if (n != h->N)
+    return fail(PPO_XP_EINVAL, "add_experience: %zu envs given, buffer has %zu (reference panics, buffer.rs:97-112)", n, h->N);
+  if (steps == 0) return 0;
+  if (!obs || !rewards || !actions || !vals || !dones || !neglogps) return fail(PPO_XP_EINVAL, "add: NULL input");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t N = h->N, D = h->D, cap = h->capacity;
+  // steps older than the last `cap` are overwritten before anyone can see them: only the ring
+  // state they leave behind matters.
+  size_t first = steps > cap ? steps - cap : 0;
+  for (size_t s = 0; s < first; ++s) advance_counter(h, h->counter % cap);
+  std::vector<float> donesf;
+  size_t s = first;
+  while (s < steps) {
+    const size_t idx = h->counter % cap;                         // buffer.rs:93
+    const size_t run = std::min(steps - s, cap - idx);           // contiguous rows idx .. idx+run
+    donesf.resize(run * N);
+    for (size_t i = 0; i < run * N; ++i) donesf[i] = (float)(uint8_t)(dones[s * N + i] != 0);  // buffer.rs:95
+    HIP_TRY(hipMemcpyAsync(h->obs + idx * N * D, obs + s * N * D, run * N * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->rewards + idx * N, rewards + s * N, run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->actions + idx * N, actions + s * N, run * N * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->values + idx * N, vals + s * N, run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->dones + idx * N, donesf.data(), run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->neglogps + idx * N, neglogps + s * N, run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));                    // host buffers are the caller's again
+    for (size_t r = 0; r < run; ++r) advance_counter(h, idx + r);
+    s += run;
+  }
+  return 0;
+}
+
+int ppo_xp_add(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions, const float *vals,
+               const uint8_t *dones, const float *neglogps, size_t n) {
+  return ppo_xp_add_many(h, obs, rewards, actions, vals, dones, neglogps, n, 1);
+}
+
+int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions, const float *vals,
+                      const float *dones_f32, const float *neglogps, size_t n) {
+  if (!h) return fail(PPO_XP_EINVAL, "add_device: handle is NULL");
+  if (n != h->N) return fail(PPO_XP_EINVAL, "add_experience: %zu envs given, buffer has %zu", n, h->N);
+  if (!obs || !rewards || !actions || !vals || !dones_f32 || !neglogps) return fail(PPO_XP_EINVAL, "add_device: NULL input");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t N = h->N, D = h->D, idx = h->counter % h->capacity;
+  HIP_TRY(hipMemcpyAsync(h->obs + idx * N * D, obs, N * D * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->rewards + idx * N, rewards, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->actions + idx * N, actions, N * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->values + idx * N, vals, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->dones + idx * N, dones_f32, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->neglogps + idx * N, neglogps, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  advance_counter(h, idx);
+  return 0;
+}
+
+void ppo_xp_reset_counter(ppo_xp *h) {                          // buffer.rs:131-133
+  if (!h) return;
+  h->counter = 0; h->have_returns = false; h->have_rec = false; h->pass_active = false;
+}
+size_t ppo_xp_len(const ppo_xp *h) { return h ? buf_len(h) : 0; }
+size_t ppo_xp_counter(const ppo_xp *h) { return h ? h->counter : 0; }
+size_t ppo_xp_last_values_idx(const ppo_xp *h) { return h ? h->last_values_idx : 0; }
+
+int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out) {
+  if (!h) return fail(PPO_XP_EINVAL, "returns: handle is NULL");
+  if (n != h->N)
+    return fail(PPO_XP_EINVAL, "returns: last_dones has %zu entries, buffer has %zu envs (reference panics, buffer.rs:194)", n, h->N);
+  if (!last_dones) return fail(PPO_XP_EINVAL, "returns: last_dones is NULL");
+  const int kind = algo & 0xff;
+  if (kind != PPO_XP_GAE_SEQUENTIAL && kind != PPO_XP_GAE_ASSOC) return fail(PPO_XP_EINVAL, "returns: unknown algo %d", algo);
+  HIP_TRY(hipSetDevice(h->device));
+  // pinned staging ring: wait only for the upload that used this slot four calls ago, so the
+  // host can keep enqueueing while the GPU still works on earlier calls
+  const unsigned slot = h->pin_next++ & 3u;
+  if (h->pin_used[slot]) HIP_TRY(hipEventSynchronize(h->pin_ev[slot]));
+  uint8_t *pin = h->last_dones_pin + (size_t)slot * n;
+  std::memcpy(pin, last_dones, n);
+  HIP_TRY(hipMemcpyAsync(h->last_dones_dev, pin, n, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipEventRecord(h->pin_ev[slot], h->stream));
+  h->pin_used[slot] = true;
+  h->pass_active = false;
+  if (int rc = run_gae(h, algo)) return rc;
+  h->have_returns = true; h->ret_len = buf_len(h);
+  if (buf_len(h) == 0) h->have_rec = true;
+  if (host_out) {
+    const size_t M = buf_len(h) * h->N;
+    if (M) HIP_TRY(hipMemcpyAsync(host_out, h->returns, M * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return 0;
+}
+
+int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out) {
+  if (!h || !out) return fail(PPO_XP_EINVAL, "views: NULL argument");
+  out->num_steps = buf_len(h) * h->N; out->obs_size = h->D;
+  out->observations = h->obs; out->actions = h->actions; out->values = h->values; out->neglogps = h->neglogps;
+  out->rewards = h->rewards; out->dones = h->dones; out->returns = h->returns; out->advantages = h->adv;
+  return 0;
+}
+
+int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64_t seed) {
+  if (!h) return fail(PPO_XP_EINVAL, "pass_begin: handle is NULL");
+  if (batch_size == 0) return fail(PPO_XP_EINVAL, "pass_begin: batch_size 0 (the reference would iterate forever)");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t M = buf_len(h) * h->N;
+  if (M) {
+    // previous upload may still be reading perm_host
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->perm_host.resize(M);
+    if (perm) {
+      for (size_t i = 0; i < M; ++i)
+        if (perm[i] >= M) return fail(PPO_XP_EINVAL, "pass_begin: perm[%zu] = %u is out of range (M = %zu)", i, perm[i], M);
+      std::memcpy(h->perm_host.data(), perm, M * sizeof(uint32_t));
+    } else {
+      shuffle_indices(seed, h->perm_host.data(), M);             // data.rs:93-95
+    }
+    HIP_TRY(hipMemcpyAsync(h->perm, h->perm_host.data(), M * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+  }
+  h->perm_cur = h->perm;
+  return pass_begin_impl(h, batch_size);
+}
+
+int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_dev) {
+  if (!h) return fail(PPO_XP_EINVAL, "pass_begin: handle is NULL");
+  if (batch_size == 0) return fail(PPO_XP_EINVAL, "pass_begin: batch_size 0 (the reference would iterate forever)");
+  if (!perm_dev) return fail(PPO_XP_EINVAL, "pass_begin_device: perm is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  h->perm_cur = perm_dev;  // borrowed, not copied: see include/ppo_xp.h
+  return pass_begin_impl(h, batch_size);
+}
+
+int ppo_xp_pass_finish(ppo_xp *h) {
+  if (!h) return fail(PPO_XP_EINVAL, "pass_finish: handle is NULL");
+  if (!h->pass_active || !h->pass_pending_finish) return fail(PPO_XP_ESTATE, "pass_finish: no pass is waiting for its statistics exchange");
+  HIP_TRY(hipSetDevice(h->device));
+  return pass_finish_impl(h);
+}
+
+int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out) {
+  if (!h || !out) return fail(PPO_XP_EINVAL, "pass_next: NULL argument");
+  if (!h->pass_active) return fail(PPO_XP_ESTATE, "pass_next: no pass (call ppo_xp_pass_begin)");
+  if (h->pass_pending_finish) return fail(PPO_XP_ESTATE, "pass_next: statistics exchange pending (call ppo_xp_pass_finish)");
+  const size_t B = h->pass_B, M = h->pass_M;
+  if (B > M || h->pass_iter >= M) return 1;                      // data.rs:117-119 -> None
+  const size_t k = h->pass_iter / B;
+  h->pass_iter += B;                                             // data.rs:126
+  out->index = k; out->batch_size = B; out->obs_size = h->D;
+  out->observations = h->obs_out + k * B * h->D;
+  out->actions = h->act_out + k * B;
+  out->values = h->val_out + k * B;
+  out->neglogps = h->nlp_out + k * B;
+  out->returns = h->ret_out + k * B;
+  out->advantages = h->adv_out + k * B;
+  out->adv_mean = 0.f; out->adv_std = 0.f;
+  return 0;
+}
+
+size_t ppo_xp_pass_num_batches(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_K : 0; }
+const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *h) { return h ? h->perm_cur : nullptr; }
+
+int ppo_xp_pass_perm_host(ppo_xp *h, uint32_t *out, size_t n) {
+  if (!h || !out) return fail(PPO_XP_EINVAL, "pass_perm_host: NULL argument");
+  if (!h->pass_active) return fail(PPO_XP_ESTATE, "pass_perm_host: no pass");
+  if (n != h->pass_M) return fail(PPO_XP_EINVAL, "pass_perm_host: n = %zu, M = %zu", n, h->pass_M);
+  HIP_TRY(hipSetDevice(h->device));
+  if (n) HIP_TRY(hipMemcpyAsync(out, h->perm_cur, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ppo_xp_pass_stats_host(ppo_xp *h, float *mean_std_out, size_t k) {
+  if (!h || !mean_std_out) return fail(PPO_XP_EINVAL, "pass_stats_host: NULL argument");
+  if (!h->pass_active || h->pass_pending_finish) return fail(PPO_XP_ESTATE, "pass_stats_host: no finished pass");
+  if (k != h->pass_K) return fail(PPO_XP_EINVAL, "pass_stats_host: k = %zu, pass has %zu minibatches", k, h->pass_K);
+  HIP_TRY(hipSetDevice(h->device));
+  if (k) HIP_TRY(hipMemcpyAsync(mean_std_out, h->stats, 2 * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ppo_xp_set_exchange(ppo_xp *h, int mode, void *nccl_comm) {
+  if (!h) return fail(PPO_XP_EINVAL, "set_exchange: handle is NULL");
+  if (mode < 0 || mode > 2) return fail(PPO_XP_EINVAL, "set_exchange: mode %d", mode);
+  if (mode == 1) {
+    if (!nccl_comm) return fail(PPO_XP_EINVAL, "set_exchange: mode 1 needs a ncclComm_t");
+    if (int rc = rccl_load()) return rc;
+  }
+  h->xmode = mode; h->comm = (mode == 1) ? nccl_comm : nullptr;
+  return 0;
+}
+
+double *ppo_xp_pass_sums_device(ppo_xp *h) { return h ? h->sums : nullptr; }
+
+int ppo_xp_rccl_unique_id(void *out128) {
+  if (!out128) return fail(PPO_XP_EINVAL, "rccl_unique_id: NULL");
+  if (int rc = rccl_load()) return rc;
+  RcclUniqueId id;
+  int e = g_rccl.GetUniqueId(&id);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(e));
+  std::memcpy(out128, &id, sizeof(id));
+  return 0;
+}
+
+int ppo_xp_rccl_comm_init(void **comm_out, const void *unique_id128, int rank, int world) {
+  if (!comm_out || !unique_id128) return fail(PPO_XP_EINVAL, "rccl_comm_init: NULL");
+  if (int rc = rccl_load()) return rc;
+  RcclUniqueId id;
+  std::memcpy(&id, unique_id128, sizeof(id));
+  void *comm = nullptr;
+  int e = g_rccl.CommInitRank(&comm, world, id, rank);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(e));
+  *comm_out = comm;
+  return 0;
+}
+
+int ppo_xp_rccl_comm_destroy(void *comm) {
+  if (!comm) return 0;
+  if (int rc = rccl_load()) return rc;
+  int e = g_rccl.CommDestroy(comm);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclCommDestroy failed: %s", g_rccl.GetErrorString(e));
+  return 0;
+}
+
+void *ppo_xp_stream(const ppo_xp *h) { return h ? (void *)h->stream : nullptr; }
+
+int ppo_xp_set_stream(ppo_xp *h, void *stream) {
+  if (!h) return fail(PPO_XP_EINVAL, "set_stream: handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
+  h->stream = (hipStream_t)stream;
+  return 0;
+}
+
+int ppo_xp_sync(ppo_xp *h) {
+  if (!h) return fail(PPO_XP_EINVAL, "sync: handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int ppo_xp_device(const ppo_xp *h) { return h ? h->device : -1; }
+
+int ppo_xp_prof_enable(ppo_xp *h, int enable) {
+  if (!h) return fail(PPO_XP_EINVAL, "prof_enable: handle is NULL");
+  h->prof = enable != 0;
+  return 0;
+}
+
+int ppo_xp_prof_collect(ppo_xp *h, double *ms_out, uint64_t *launches_out) {
+  if (!h || !ms_out || !launches_out) return fail(PPO_XP_EINVAL, "prof_collect: NULL argument");
+  HIP_TRY(hipSetDevice(h->device));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < PPO_XP_K_COUNT; ++i) { ms_out[i] = 0.0; launches_out[i] = 0; }
+  for (auto &r : h->prof_recs) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { ms_out[r.kid] += ms; launches_out[r.kid] += 1; }
+    h->ev_pool.push_back(r.a); h->ev_pool.push_back(r.b);
+  }
+  h->prof_recs.clear();
+  return 0;
+}
+
+int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
+  if (!h || !name) return fail(PPO_XP_EINVAL, "set_tunable: NULL argument");
+  std::string n(name);
+  if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
+  else if (n == "gather_unroll" && (value == 4 || value == 8 || value == 16)) h->gather_unroll = value;
+  else if (n == "gae_unroll" && (value == 4 || value == 8 || value == 16)) h->gae_unroll = value;
+  else if (n == "carry_waves" && (value == 4 || value == 8 || value == 16)) h->carry_waves = value;
+  else return fail(PPO_XP_EINVAL, "set_tunable: unknown name or bad value: %s = %ld", name, value);
+  return 0;
+}
+
+}  // extern "C"

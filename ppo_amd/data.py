@@ -1,0 +1,132 @@
+"""ExperienceBatch / ExperienceBatcher — host-side mirror of ppo/src/model/data.rs over the C ABI.
+
+  ExperienceBatch            data.rs:4-12      ExperienceBatcher::new   data.rs:22-78
+  ExperienceBatcher::len     data.rs:80-82     into_iter (shuffle)      data.rs:85-103
+  Iterator::next             data.rs:115-192
+
+Differences from the reference that a caller can see, all deliberate:
+  * the master copy (`set`, data.rs:37-70) is never made: the buffer is already on the device and
+    `advantages = returns - values` (data.rs:62) was fused into the GAE kernel;
+  * one `iter()` gathers all K minibatches in one launch; `next` hands out slices of the slabs;
+  * the shuffle is seedable (`seed=` / `perm=`); the reference's thread_rng() is not reproducible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import PpoXpPanic, check
+from .buffer import ExperienceBuffer, device_tensor
+
+
+@dataclass
+class ExperienceBatch:
+    """data.rs:4-12 — all fields are device tensors."""
+    observations: "torch.Tensor"  # [batch_size, obs_size] f32
+    actions: "torch.Tensor"       # [batch_size] i64 (usize in the reference)
+    values: "torch.Tensor"        # [batch_size]
+    neglogps: "torch.Tensor"      # [batch_size]
+    returns: "torch.Tensor"       # [batch_size]
+    advantages: "torch.Tensor"    # [batch_size], standardised per minibatch (data.rs:157-164)
+
+
+class ExperienceBatcher:
+    """data.rs:14-83.  Holds the buffer whose views it was built from and a batch size."""
+
+    _seed_counter = itertools.count(0x5EED)
+
+    def __init__(self, buffer: ExperienceBuffer, batch_size: int, seed: int | None = None):
+        self.buffer, self.batch_size = buffer, int(batch_size)
+        self._seed = seed
+        self._L = _lib.load()
+
+    @classmethod
+    def new(cls, observations, actions, values, neglogps, returns, batch_size, cache=None, seed=None):
+        """ExperienceBatcher::new (data.rs:22-30).  The five views must be the ones handed out by ONE
+        ExperienceBuffer (training_views() + returns()); `cache` is accepted for signature parity and
+        ignored (the kernels write device minibatches directly, data.rs:166-182 has no counterpart)."""
+        owners = {id(getattr(t, "_ppo_owner", None)) for t in (observations, actions, values, neglogps, returns)}
+        owner = getattr(observations, "_ppo_owner", None)
+        if owner is None or len(owners) != 1:
+            raise PpoXpPanic(_lib.EINVAL, "ExperienceBatcher.new: pass the views of one ExperienceBuffer")
+        return cls(owner, batch_size, seed)
+
+    def __len__(self):
+        """data.rs:80-82: number of transitions M."""
+        return len(self.buffer) * self.buffer.num_envs
+
+    def num_batches(self):
+        M, B = len(self), self.batch_size
+        return 0 if (B > M or B <= 0) else (M + B - 1) // B
+
+    def __iter__(self):
+        return self.into_iter()
+
+    def into_iter(self, seed: int | None = None, perm=None):
+        """data.rs:91-102: a fresh permutation per pass.  perm: optional host u32 array or CUDA
+        int32 tensor of M indices."""
+        return ExperienceBatcherIterator(self, seed, perm)
+
+
+class ExperienceBatcherIterator:
+    """data.rs:105-193."""
+
+    def __init__(self, batcher: ExperienceBatcher, seed=None, perm=None):
+        self.batcher = batcher
+        buf, L = batcher.buffer, batcher._L
+        h = buf.handle
+        B = batcher.batch_size
+        if perm is not None and hasattr(perm, "is_cuda") and perm.is_cuda:
+            import torch
+            if perm.numel() != len(batcher) or perm.dtype not in (torch.int32,) or not perm.is_contiguous():
+                raise PpoXpPanic(_lib.EINVAL, "perm: contiguous CUDA int32 tensor of M indices expected")
+            torch.cuda.current_stream(buf.device).synchronize()
+            check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
+        elif perm is not None:
+            p = np.ascontiguousarray(perm, dtype=np.uint32)
+            if p.shape != (len(batcher),):
+                raise PpoXpPanic(_lib.EINVAL, "perm: M indices expected")
+            check(L.ppo_xp_pass_begin(h, B, p.ctypes.data_as(C.c_void_p), 0))
+        else:
+            if seed is None:
+                seed = batcher._seed if batcher._seed is not None else next(ExperienceBatcher._seed_counter)
+                if batcher._seed is not None:
+                    batcher._seed += 1  # a new permutation per pass (training.rs:204-205)
+            check(L.ppo_xp_pass_begin(h, B, None, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> ExperienceBatch:
+        import torch
+        buf = self.batcher.buffer
+        v = _lib.BatchView()
+        rc = check(self.batcher._L.ppo_xp_pass_next(buf.handle, C.byref(v)))
+        if rc == 1:
+            raise StopIteration
+        if v.index == 0:
+            buf.sync()
+        B, D, d = v.batch_size, v.obs_size, buf.device
+        f32, i64 = torch.float32, torch.int64
+        return ExperienceBatch(
+            device_tensor(v.observations, (B, D), f32, d, buf), device_tensor(v.actions, (B,), i64, d, buf),
+            device_tensor(v.values, (B,), f32, d, buf), device_tensor(v.neglogps, (B,), f32, d, buf),
+            device_tensor(v.returns, (B,), f32, d, buf), device_tensor(v.advantages, (B,), f32, d, buf))
+
+    def perm(self) -> np.ndarray:
+        """The permutation of this pass (host copy)."""
+        M = len(self.batcher)
+        out = np.empty(M, np.uint32)
+        check(self.batcher._L.ppo_xp_pass_perm_host(self.batcher.buffer.handle, out.ctypes.data_as(C.c_void_p), M))
+        return out
+
+    def stats(self) -> np.ndarray:
+        """[K, 2] (mean, unbiased std) used for each minibatch."""
+        K = self.batcher._L.ppo_xp_pass_num_batches(self.batcher.buffer.handle)
+        out = np.empty((K, 2), np.float32)
+        check(self.batcher._L.ppo_xp_pass_stats_host(self.batcher.buffer.handle, out.ctypes.data_as(C.c_void_p), K))
+        return out

@@ -1,0 +1,356 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (ppo_amd -> libppo_xp.so),
+against the CPU oracle on the same seeded inputs, the reference's own test vectors and the
+committed golden fixtures.
+
+Bars (BASELINE.json north_star):
+  * ring state, views, permutation indices, gathered rows, actions: bit-exact;
+  * sequential-scan returns / advantages: bit-exact (north star asks for <= 1e-6 relative);
+  * standardised advantages: the reduction ORDER of the reference is unpinned (un-vendored dfdx
+    fork), the kernel sums in fp64 -> compared within ATOL_STD of the fp32-sequential restatement
+    and within ATOL_STD64 of the fp64 oracle (values are O(1) after standardisation);
+  * associative-scan returns: |err| <= RTOL_ASSOC * max(1, |ret|).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KATS = json.load(open(os.path.join(HERE, "golden", "reference_kats.json")))
+
+ATOL_STD = 2e-5     # vs fp32 sequential oracle, B <= 16384 (its own rounding error dominates)
+ATOL_STD64 = 2e-6   # vs fp64 oracle
+RTOL_ASSOC = 2e-6
+
+
+@pytest.fixture(scope="module")
+def xp():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import ppo_amd
+    return ppo_amd
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32 if a.dtype.itemsize == 4 else np.uint64)
+
+
+def fill(buf, rollout, steps=None):
+    T = rollout["rewards"].shape[0] if steps is None else steps
+    for t in range(T):
+        buf.add_experience(rollout["obs"][t], rollout["rewards"][t], rollout["actions"][t], rollout["values"][t],
+                           rollout["dones"][t], rollout["neglogps"][t])
+
+
+def both(xp, oracle, T, N, D, cap, seed, p_done=0.05, steps=None, bulk=False):
+    from ppo_amd import synth
+    steps = T if steps is None else steps
+    r = synth.rollout(steps, N, D, seed, p_done)
+    g = xp.ExperienceBuffer(N, D, cap)
+    o = oracle.OracleBuffer(N, D, cap)
+    if bulk:
+        g.add_many(r["obs"], r["rewards"], r["actions"], r["values"], r["dones"], r["neglogps"])
+    else:
+        fill(g, r)
+    fill(o, r)
+    return g, o, r
+
+
+def check_pass(xp, oracle, g, o, last_dones, B, seed=None, perm=None, algo=0, exact_returns=True):
+    """Runs returns + one shuffled pass on both sides and compares everything."""
+    N, D = g.num_envs, g.obs_size
+    ret_g = g.returns(last_dones, algo=algo).cpu().numpy()
+    ret_o = o.returns(last_dones)
+    if exact_returns:
+        np.testing.assert_array_equal(bits(ret_g), bits(ret_o))
+    else:
+        assert np.all(np.abs(ret_g - ret_o) <= RTOL_ASSOC * np.maximum(1.0, np.abs(ret_o)))
+    obs_o, act_o, val_o, nlp_o = o.training_views()
+    obs_g, act_g, val_g, nlp_g = (t.cpu().numpy() for t in g.training_views())
+    np.testing.assert_array_equal(bits(obs_g), bits(obs_o))
+    np.testing.assert_array_equal(act_g.astype(np.uint64), act_o)
+    np.testing.assert_array_equal(bits(val_g), bits(val_o))
+    np.testing.assert_array_equal(bits(nlp_g), bits(nlp_o))
+    adv_o = oracle.advantages(ret_g, val_o)  # data.rs:62 on the returns actually produced
+    np.testing.assert_array_equal(bits(g.advantages().cpu().numpy()), bits(adv_o))
+
+    M = len(o) * N
+    batcher = xp.ExperienceBatcher.new(*g.training_views(), g.returns(last_dones, algo=algo), B)
+    assert len(batcher) == M
+    it = batcher.into_iter(seed=seed, perm=perm)
+    batches = list(it)
+    windows = oracle.batch_windows(M, B)
+    assert len(batches) == len(windows) == oracle.num_batches(M, B)
+    if not windows:
+        return
+    p = it.perm()
+    if perm is not None:
+        np.testing.assert_array_equal(p, np.asarray(perm, np.uint32))
+    else:
+        np.testing.assert_array_equal(p, oracle.shuffle(seed, M))   # bit-exact permutation indices
+    stats = it.stats()
+    for k, ((s, e), b) in enumerate(zip(windows, batches)):
+        idx = p[s:e]
+        np.testing.assert_array_equal(bits(b.observations.cpu().numpy()), bits(oracle.gather_f32(obs_o, idx)))
+        np.testing.assert_array_equal(b.actions.cpu().numpy().astype(np.uint64), oracle.gather_u64(act_o, idx))
+        np.testing.assert_array_equal(bits(b.values.cpu().numpy()), bits(oracle.gather_f32(val_o, idx)))
+        np.testing.assert_array_equal(bits(b.neglogps.cpu().numpy()), bits(oracle.gather_f32(nlp_o, idx)))
+        np.testing.assert_array_equal(bits(b.returns.cpu().numpy()), bits(oracle.gather_f32(ret_g, idx)))
+        a = oracle.gather_f32(adv_o, idx)
+        want32, m32, s32 = oracle.standardize(a)
+        want64, m64, s64 = oracle.standardize_f64(a)
+        got = b.advantages.cpu().numpy()
+        if B == 1:
+            assert np.isnan(got).all() and np.isnan(want32).all()    # 0 * inf, as the reference
+            continue
+        if s64 > 1e-3:
+            np.testing.assert_allclose(got, want64, rtol=0, atol=ATOL_STD64 * max(1.0, np.abs(want64).max()))
+            np.testing.assert_allclose(got, want32, rtol=0, atol=ATOL_STD * max(1.0, np.abs(want32).max()))
+        assert abs(stats[k, 0] - m64) <= 1e-6 * max(1.0, abs(m64)) and abs(stats[k, 1] - s64) <= 1e-6 * max(1.0, s64)
+
+
+# ---- the reference's own unit tests, run against the HIP path -------------------------------
+
+def _kat_fill(buf, kat):
+    for name, times in kat["inserts"]:
+        s = KATS["steps"][name]
+        for _ in range(times):
+            buf.add_experience(s["obs"], s["rewards"], s["actions"], s["vals"], s["dones"], s["neglogps"])
+
+
+@pytest.mark.parametrize("name", ["exp_buffer_below_capacity", "exp_buffer_at_capacity", "exp_buffer_over_capacity"])
+def test_reference_buffer_tests(xp, name):
+    """buffer.rs:233-409."""
+    kat = KATS[name]
+    buf = xp.ExperienceBuffer.new(kat["num_envs"], kat["obs_size"], kat["capacity"])
+    _kat_fill(buf, kat)
+    obs, actions, values, neglogps = buf.training_views()
+    assert tuple(obs.shape) == (len(kat["obs"]), kat["obs_size"])
+    np.testing.assert_array_equal(obs.cpu().numpy(), np.array(kat["obs"], np.float32))
+    np.testing.assert_array_equal(actions.cpu().numpy(), np.array(kat["actions"]))
+    np.testing.assert_array_equal(values.cpu().numpy(), np.array(kat["values"], np.float32))
+    np.testing.assert_array_equal(neglogps.cpu().numpy(), np.array(kat["neglogps"], np.float32))
+    if "returns_len" in kat:
+        assert tuple(buf.returns(kat["last_dones"]).shape) == (kat["returns_len"],)
+
+
+def test_reference_returns_sanity(xp):
+    """buffer.rs:412-458 + the exact fp32 bit patterns of SURVEY.md section 4."""
+    kat = KATS["exp_buffer_returns_sanity"]
+    buf = xp.ExperienceBuffer.new(kat["num_envs"], kat["obs_size"], kat["capacity"])
+    _kat_fill(buf, kat)
+    ret = buf.returns(kat["last_dones"], to_host=True)
+    for r, (lo, hi) in zip(ret, kat["returns_open_intervals"]):
+        assert lo < r < hi
+    want = np.array([int(h, 16) for h in KATS["survey_fp32_restatement"]["returns_hex_last_dones_true"]], np.uint32)
+    np.testing.assert_array_equal(bits(ret), want)
+    ret2 = buf.returns([False, False], to_host=True)
+    np.testing.assert_allclose(ret2, KATS["survey_fp32_restatement"]["returns_last_dones_false"], rtol=0, atol=5e-7)
+    assert buf.training_views()[0].shape[0] == ret.shape[0]
+
+
+def test_reference_batcher_sanity(xp):
+    """data.rs:210-270: 10 rows, batch 6 -> 2 iterations, every row seen."""
+    kat = KATS["batcher_sanity"]
+    buf = xp.ExperienceBuffer.new(kat["num_envs"], kat["obs_size"], kat["capacity"])
+    for i in range(kat["steps"]):
+        buf.add_experience([[0.0 + i, 1.0, 2.0], [100.0 + i, 2.0, 3.0]], kat["rewards"], kat["actions"], kat["vals"],
+                           kat["dones"], kat["neglogps"])
+    observations, actions, values, neglogps = buf.training_views()
+    returns = buf.returns(kat["last_dones"])
+    batcher = xp.ExperienceBatcher.new(observations, actions, values, neglogps, returns, kat["batch_size"], None)
+    seen, n = set(), 0
+    for batch in batcher:
+        assert tuple(batch.observations.shape) == (kat["batch_size"], kat["obs_size"])
+        seen |= {int(round(float(x))) for x in batch.observations[:, 0].cpu()}
+        n += 1
+    assert n == kat["num_iterations"]
+    assert seen == set(kat["seen_rounded_obs0"])
+    # a second pass draws a new permutation (training.rs:204-205)
+    p1 = batcher.into_iter(seed=1).perm()
+    p2 = batcher.into_iter(seed=2).perm()
+    assert not np.array_equal(p1, p2)
+
+
+# ---- seeded parity against the oracle ---------------------------------------------------------
+
+@pytest.mark.parametrize("T,N,D,B", [
+    (128, 8, 4, 256),      # C1
+    (17, 70, 3, 500),      # N % 64 != 0, scalar obs rows, overlapping tail
+    (5, 2, 3, 6),          # the reference's batcher_sanity shape
+    (9, 130, 6, 64),       # float2 rows, tail of 64-row waves
+    (3, 64, 64, 192),      # D = 64 (16 lanes per row)
+    (2, 33, 256, 66),      # D = 256 (one row per wave instruction)
+    (4, 5, 20, 7),         # non power-of-two float4 count per row
+    (1, 1, 1, 1),          # single transition: standardisation is NaN (n = 1)
+    (6, 3, 2, 18),         # B == M: one batch
+    (6, 3, 2, 19),         # B > M: empty pass (data.rs:117)
+])
+def test_seeded_parity(xp, oracle, T, N, D, B):
+    g, o, r = both(xp, oracle, T, N, D, T, seed=T * 1000 + N, p_done=0.1)
+    check_pass(xp, oracle, g, o, r["last_dones"], B, seed=0xC0FFEE + N)
+    g.close()
+
+
+def test_parity_bulk_insert_and_explicit_perm(xp, oracle):
+    g, o, r = both(xp, oracle, 40, 96, 8, 40, seed=11, bulk=True)
+    M = 40 * 96
+    perm = np.random.default_rng(3).permutation(M).astype(np.uint32)
+    check_pass(xp, oracle, g, o, r["last_dones"], 1000, perm=perm)
+    import torch
+    it = xp.ExperienceBatcher(g, 1000).into_iter(perm=torch.from_numpy(perm.astype(np.int32)).cuda())
+    np.testing.assert_array_equal(it.perm(), perm)
+    g.close()
+
+
+def test_parity_partial_and_wrapped_ring(xp, oracle):
+    """Below capacity (len < cap) and after a ring wrap: storage order, last_values_idx bootstrap
+    (buffer.rs:204) in the middle of the buffer, reset_counter keeping the data (buffer.rs:131)."""
+    g, o, r = both(xp, oracle, 0, 10, 5, cap=8, seed=21, steps=5)          # 5 of 8 rows
+    assert len(g) == len(o) == 5
+    check_pass(xp, oracle, g, o, r["last_dones"], 16, seed=1)
+    g.close()
+    g, o, r = both(xp, oracle, 0, 10, 5, cap=8, seed=22, steps=21)         # wraps: 21 % 8 = 5
+    assert len(g) == len(o) == 8 and g.last_values_idx == o.last_values_idx == 4
+    assert g.counter == 8 + 21 % 8
+    check_pass(xp, oracle, g, o, r["last_dones"], 16, seed=2)
+    g.reset_counter(); o.reset_counter()
+    assert len(g) == len(o) == 0
+    from ppo_amd import synth
+    r2 = synth.rollout(3, 10, 5, 23, 0.1)
+    fill(g, r2); fill(o, r2)
+    assert len(g) == 3 and g.last_values_idx == 2
+    check_pass(xp, oracle, g, o, r2["last_dones"], 7, seed=3)
+    g.close()
+    g, o, r = both(xp, oracle, 0, 10, 5, cap=8, seed=24, steps=21, bulk=True)  # add_many across the wrap
+    assert g.counter == 8 + 21 % 8 and g.last_values_idx == 4
+    check_pass(xp, oracle, g, o, r["last_dones"], 16, seed=4)
+    g.close()
+
+
+def test_done_flags_cut_the_recurrence(xp, oracle):
+    """All-done and never-done extremes, and last_dones all true / all false."""
+    from ppo_amd import synth
+    for p_done, ld in ((1.0, 1), (0.0, 0), (0.5, 1), (0.5, 0)):
+        r = synth.rollout(16, 70, 2, 31, p_done)
+        g, o = xp.ExperienceBuffer(70, 2, 16), oracle.OracleBuffer(70, 2, 16)
+        fill(g, r); fill(o, r)
+        last = np.full(70, ld, np.uint8)
+        np.testing.assert_array_equal(bits(g.returns(last, to_host=True)), bits(o.returns(last)))
+        g.close()
+
+
+def test_special_values_propagate_bitwise(xp, oracle):
+    """inf / nan / denormal inputs: same bits as the CPU (no flush-to-zero, no fast-math)."""
+    from ppo_amd import synth
+    r = synth.rollout(8, 64, 4, 41, 0.1)
+    r["rewards"][3, 5] = np.inf
+    r["values"][2, 7] = np.float32(1e-41)       # denormal
+    r["rewards"][1, 9] = np.float32(-3e-42)
+    r["values"][6, 11] = np.nan
+    r["obs"][0, 0, 0] = np.float32(1e-45)
+    g, o = xp.ExperienceBuffer(64, 4, 8), oracle.OracleBuffer(64, 4, 8)
+    fill(g, r); fill(o, r)
+    a, b = g.returns(r["last_dones"], to_host=True), o.returns(r["last_dones"])
+    nan = np.isnan(b)
+    np.testing.assert_array_equal(np.isnan(a), nan)
+    np.testing.assert_array_equal(bits(a)[~nan], bits(b)[~nan])
+    it = xp.ExperienceBatcher(g, 128).into_iter(seed=5)
+    p = it.perm()
+    for k, batch in enumerate(it):
+        np.testing.assert_array_equal(bits(batch.observations.cpu().numpy()),
+                                      bits(r["obs"].reshape(-1, 4)[p[k * 128:(k + 1) * 128]]))
+    g.close()
+
+
+def test_large_actions_are_kept(xp, oracle):
+    """actions are usize in the reference (buffer.rs:33): 64-bit values survive the gather."""
+    from ppo_amd import synth
+    r = synth.rollout(4, 6, 2, 51, 0.0)
+    r["actions"][1, 2] = np.uint64(2**40 + 7)
+    r["actions"][3, 5] = np.uint64(2**63 - 1)
+    g = xp.ExperienceBuffer(6, 2, 4)
+    fill(g, r)
+    g.returns(r["last_dones"])
+    it = xp.ExperienceBatcher(g, 24).into_iter(seed=9)
+    p = it.perm()
+    (batch,) = list(it)
+    np.testing.assert_array_equal(batch.actions.cpu().numpy().astype(np.uint64), r["actions"].reshape(-1)[p])
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["c1_path.npz", "c_small_path.npz"])
+def test_golden_fixtures(xp, name):
+    """Committed golden vectors (tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(HERE, "golden", name))
+    T, N, D, B = (int(x) for x in z["dims"])
+    g = xp.ExperienceBuffer(N, D, T)
+    g.add_many(z["obs"], z["rewards"], z["actions"], z["values"], z["dones"], z["neglogps"])
+    ret = g.returns(z["last_dones"], to_host=True)
+    np.testing.assert_array_equal(bits(ret), bits(z["out_returns"]))
+    np.testing.assert_array_equal(bits(g.advantages().cpu().numpy()), bits(z["out_adv"]))
+    it = xp.ExperienceBatcher(g, B).into_iter(seed=int(z["seed"]))
+    np.testing.assert_array_equal(it.perm(), z["perm"])
+    batches = list(it)
+    cat = lambda f: np.concatenate([getattr(b, f).cpu().numpy() for b in batches])
+    np.testing.assert_array_equal(bits(cat("observations")), bits(z["out_obs"]))
+    np.testing.assert_array_equal(cat("actions").astype(np.uint64), z["out_actions"])
+    np.testing.assert_array_equal(bits(cat("values")), bits(z["out_values"]))
+    np.testing.assert_array_equal(bits(cat("neglogps")), bits(z["out_neglogps"]))
+    np.testing.assert_array_equal(bits(cat("returns")), bits(z["out_ret"]))
+    np.testing.assert_allclose(cat("advantages"), z["out_advn"], rtol=0, atol=ATOL_STD * 5)
+    g.close()
+
+
+# ---- associative scan (K2) ----------------------------------------------------------------------
+
+@pytest.mark.parametrize("T,N,chunk", [(128, 8, 0), (1000, 70, 0), (1000, 70, 7), (4096, 64, 64), (513, 3, 512), (64, 130, 1)])
+def test_assoc_scan_close_to_sequential(xp, oracle, T, N, chunk):
+    import ppo_amd
+    g, o, r = both(xp, oracle, T, N, 1, T, seed=61 + T, p_done=0.02, bulk=True)
+    algo = ppo_amd.GAE_ASSOC | ppo_amd.gae_chunk(chunk)
+    a = g.returns(r["last_dones"], algo=algo, to_host=True)
+    b = o.returns(r["last_dones"])
+    err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+    assert err.max() <= RTOL_ASSOC, err.max()
+    # and the rest of the path runs on top of it
+    check_pass(xp, oracle, g, o, r["last_dones"], 256, seed=5, algo=algo, exact_returns=False)
+    g.close()
+
+
+def test_no_pack_then_pass(xp, oracle):
+    """PPO_XP_GAE_NO_PACK returns() followed by a pass builds the records lazily."""
+    import ppo_amd
+    g, o, r = both(xp, oracle, 12, 40, 4, 12, seed=71)
+    check_pass(xp, oracle, g, o, r["last_dones"], 100, seed=8, algo=ppo_amd.GAE_NO_PACK)
+    g.close()
+
+
+# ---- error behaviour (where the reference panics) -----------------------------------------------
+
+def test_panics(xp):
+    buf = xp.ExperienceBuffer.new(2, 3, 3)
+    s = KATS["steps"]["s1"]
+    with pytest.raises(AssertionError):      # buffer.rs:97: obs.len() != NUM_ENVS
+        buf.add_experience(s["obs"][:1], s["rewards"], s["actions"], s["vals"], s["dones"], s["neglogps"])
+    with pytest.raises(AssertionError):      # buffer.rs:100
+        buf.add_experience(s["obs"], s["rewards"] + [0.0], s["actions"], s["vals"], s["dones"], s["neglogps"])
+    assert len(buf) == 0                     # nothing was inserted
+    buf.add_experience(s["obs"], s["rewards"], s["actions"], s["vals"], s["dones"], s["neglogps"])
+    with pytest.raises(AssertionError):      # buffer.rs:194
+        buf.returns([True])
+    with pytest.raises(xp.PpoXpError):       # pass before returns
+        xp.ExperienceBatcher(buf, 2).into_iter(seed=1)
+    buf.returns([True, False])
+    with pytest.raises(AssertionError):      # batch_size 0
+        xp.ExperienceBatcher(buf, 0).into_iter(seed=1)
+    with pytest.raises(AssertionError):      # perm entry out of range
+        xp.ExperienceBatcher(buf, 2).into_iter(perm=np.array([0, 5], np.uint32))
+    assert list(xp.ExperienceBatcher(buf, 3).into_iter(seed=1)) == []   # B > M -> None (data.rs:117)
+    with pytest.raises(xp.PpoXpError):
+        xp.ExperienceBuffer(0, 3, 3)
+    buf.close()
