@@ -90,12 +90,36 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime: torch wheels bundle their own libamdhip64.so (same
+    soname as /opt/rocm's).  Whichever copy initialises the GPU first leaves the other without
+    devices, so when torch is installed its copy is mapped (RTLD_GLOBAL) before libppo_xp.so,
+    whose DT_NEEDED libamdhip64.so.7 then binds to it.  Without torch the system runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load() -> C.CDLL:
     """dlopen libppo_xp.so and type every entry point.  Raises if the library is not built."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PpoXpError(ENODEV, f"{LIB_PATH} is not built (run `make -C ppo_amd/csrc`); there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol

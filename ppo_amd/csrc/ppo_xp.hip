@@ -383,8 +383,10 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
   if (num_envs > 0x7FFFFFFFull || obs_size > 0x00FFFFFFull || capacity > 0x7FFFFFFFull)
     return fail(PPO_XP_EINVAL, "create: dimension too large");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(PPO_XP_ENODEV, "create: no HIP device (this library has no CPU path)");
+  hipError_t de = hipGetDeviceCount(&ndev);
+  if (de != hipSuccess || ndev <= 0)
+    return fail(PPO_XP_ENODEV, "create: no HIP device (hipGetDeviceCount: %s, %d devices); this library has no CPU path",
+                hipGetErrorString(de), ndev);
   if (device < 0 || device >= ndev) return fail(PPO_XP_ENODEV, "create: device %d of %d", device, ndev);
   HIP_TRY(hipSetDevice(device));
   ppo_xp *h = new (std::nothrow) ppo_xp();
