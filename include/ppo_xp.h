@@ -189,13 +189,13 @@ int ppo_xp_device(const ppo_xp *h);
  * enable != 0 starts recording an event pair around every kernel launch; collect
  * synchronises, adds up elapsed ms and launch counts per kernel id and resets. */
 enum { PPO_XP_K_GAE = 0, PPO_XP_K_GAE_SUMMARY, PPO_XP_K_GAE_CARRY, PPO_XP_K_PACK, PPO_XP_K_GATHER,
-       PPO_XP_K_FINALIZE, PPO_XP_K_NORMALIZE, PPO_XP_K_COUNT };
+       PPO_XP_K_FINALIZE, PPO_XP_K_NORMALIZE, PPO_XP_K_SCALARS, PPO_XP_K_COUNT };
 int ppo_xp_prof_enable(ppo_xp *h, int enable);
 int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launches_out /*[K_COUNT]*/);
 const char *ppo_xp_kernel_name(int kernel_id);
 
-/* Tunables (A/B measurements in one process): "gather_nt" 0/1, "gather_unroll" 1/2/4/8,
- * "gae_unroll" ... Unknown names => PPO_XP_EINVAL. */
+/* Tunables (A/B measurements in one process): "gather_nt" 0/1, "gather_block" 64/256,
+ * "gae_unroll" 4/8/16, "carry_waves" 4/8/16.  Unknown names or values => PPO_XP_EINVAL. */
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
 
 const char *ppo_xp_last_error(void);

@@ -13,9 +13,10 @@ LIB_PATH = os.path.join(_HERE, "libppo_xp.so")
 
 OK, EINVAL, ENOMEM, EIO, ENODEV, ESTATE = 0, -22, -12, -5, -19, -1
 GAE_SEQUENTIAL, GAE_ASSOC, GAE_NO_PACK = 0, 1, 0x100
-K_NAMES = ("gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records", "gather", "finalize_stats", "normalize")
-K_GAE, K_GAE_SUMMARY, K_GAE_CARRY, K_PACK, K_GATHER, K_FINALIZE, K_NORMALIZE = range(7)
-K_COUNT = 7
+K_NAMES = ("gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records", "gather", "finalize_stats", "normalize",
+           "scalar_gather")
+K_GAE, K_GAE_SUMMARY, K_GAE_CARRY, K_PACK, K_GATHER, K_FINALIZE, K_NORMALIZE, K_SCALARS = range(8)
+K_COUNT = 8
 
 
 def gae_chunk(length: int) -> int:

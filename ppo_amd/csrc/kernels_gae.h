@@ -15,14 +15,27 @@
 
 namespace ppoxp {
 
-// Packed per-transition record read by the gather kernel: ONE 32-byte sector per gathered row
-// instead of four scattered 4/8-byte reads (values, neglogps, returns, actions).
-struct __attribute__((aligned(32))) Rec {
-  float v, nlp, ret, adv;  // value, neglogp, fl(A+v), fl(fl(A+v)-v)
-  int64_t act;             // usize in the reference (buffer.rs:33)
-  int64_t pad;
+// Packed per-transition record read by the scalar gather: ONE 16-byte access per gathered row
+// instead of four scattered 4/8-byte reads (values, neglogps, returns, actions).  adv' is not
+// stored: the gather recomputes fl(ret - v), the very operation of data.rs:62.
+// Actions are usize in the reference (buffer.rs:33).  The record keeps the low 32 bits; an action
+// that does not fit (or equals the escape value itself) is stored as kRecActEscape and the gather
+// fetches the full 64-bit value from the actions stream for that one row.
+struct __attribute__((aligned(16))) Rec {
+  float v, nlp, ret;
+  uint32_t act;
 };
-static_assert(sizeof(Rec) == 32, "Rec must be one 32-byte sector");
+static_assert(sizeof(Rec) == 16, "Rec must be 16 bytes");
+constexpr uint32_t kRecActEscape = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void store_rec(Rec *dst, float v, float nlp, float ret, int64_t act) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  const uint64_t a = (uint64_t)act;
+  u32x4_t q;
+  q.x = __float_as_uint(v); q.y = __float_as_uint(nlp); q.z = __float_as_uint(ret);
+  q.w = a >= (uint64_t)kRecActEscape ? kRecActEscape : (uint32_t)a;
+  *reinterpret_cast<u32x4_t *>(dst) = q;
+}
 
 struct GaeArgs {
   const float *rewards, *values, *dones, *neglogps;  // [T, N]
@@ -34,6 +47,7 @@ struct GaeArgs {
   float *sumP, *sumQ;                                // [C, N] chunk summaries (assoc)
   unsigned N, len, lvi, chunk;                       // chunk = time steps per blockIdx.y
   float gamma, gl;                                   // gl = fl(gamma*lambda)  (buffer.rs:219)
+  int nt;                                            // non-temporal inputs / returns / adv (records keep the default policy)
 };
 
 // One time step of buffer.rs:217-222, in the reference's rounding order.
@@ -81,10 +95,17 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
     for (int u = 0; u < U; ++u) {
       int t = max(t_top - u, t_lo);            // clamped: tail re-reads row t_lo (cached)
       size_t i = (size_t)t * N + e;
-      r[u] = a.rewards[i];
-      v[u] = a.values[i];
-      d[u] = a.dones[i];
-      if (PACK) { nl[u] = a.neglogps[i]; ac[u] = a.actions[i]; }
+      if (a.nt) {   // wave-uniform: streams read once must not push the records out of the Infinity Cache
+        r[u] = __builtin_nontemporal_load(a.rewards + i);
+        v[u] = __builtin_nontemporal_load(a.values + i);
+        d[u] = __builtin_nontemporal_load(a.dones + i);
+        if (PACK) { nl[u] = __builtin_nontemporal_load(a.neglogps + i); ac[u] = __builtin_nontemporal_load(a.actions + i); }
+      } else {
+        r[u] = a.rewards[i];
+        v[u] = a.values[i];
+        d[u] = a.dones[i];
+        if (PACK) { nl[u] = a.neglogps[i]; ac[u] = a.actions[i]; }
+      }
     }
   };
 
@@ -102,15 +123,9 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
         float ret, adv;
         gae_step(rc[u], vc[u], v_next, nnt_next, a.gamma, a.gl, A, ret, adv);
         size_t i = (size_t)t * N + e;
-        a.returns[i] = ret;
-        a.adv[i] = adv;
-        if (PACK) {
-          float4 lo = make_float4(vc[u], nlc[u], ret, adv);
-          longlong2 hi; hi.x = acc[u]; hi.y = 0;
-          float4 *dst = reinterpret_cast<float4 *>(a.rec + i);
-          dst[0] = lo;
-          *reinterpret_cast<longlong2 *>(dst + 1) = hi;
-        }
+        if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
+        else { a.returns[i] = ret; a.adv[i] = adv; }
+        if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
         v_next = vc[u];
         nnt_next = 1.0f - dc[u];
       }
@@ -226,15 +241,10 @@ __global__ __launch_bounds__(64 * W) void gae_carry_scan_kernel(const float *__r
 __global__ __launch_bounds__(256) void pack_records_kernel(const float *__restrict__ values,
                                                            const float *__restrict__ neglogps,
                                                            const float *__restrict__ returns,
-                                                           const float *__restrict__ adv,
                                                            const int64_t *__restrict__ actions,
                                                            Rec *__restrict__ rec, size_t M) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
-    float4 lo = make_float4(values[i], neglogps[i], returns[i], adv[i]);
-    longlong2 hi; hi.x = actions[i]; hi.y = 0;
-    float4 *dst = reinterpret_cast<float4 *>(rec + i);
-    dst[0] = lo;
-    *reinterpret_cast<longlong2 *>(dst + 1) = hi;
+    store_rec(rec + i, values[i], neglogps[i], returns[i], actions[i]);
   }
 }
 

@@ -1,15 +1,23 @@
 // Minibatch gather + advantage statistics + standardisation kernels for gfx950 (MI355X).
-// HBM-bound byte movement: no MFMA, no LDS tiling (nothing is reused); what matters is whole
-// 16-byte-per-lane accesses, many rows in flight per wave and one sector per random read.
+// HBM-bound byte movement: no MFMA, no LDS tiling (nothing is reused).
 //
 // Replaces Iterator::next of ExperienceBatcherIterator (ppo/src/model/data.rs:115-192):
 //   5 x gather (data.rs:137-156), the advantage gather + standardisation (data.rs:157-164,
 //   correct_std data.rs:196-200) and the six uploads into the device cache (data.rs:166-182,
-//   not needed here: the kernel writes the device minibatch directly).
+//   not needed here: the kernels write the device minibatch directly).
 //
-// One launch gathers ALL K minibatches of a pass: minibatch k is rows [k*B, (k+1)*B) of the
-// output slabs and takes its indices from perm[start_k .. start_k+B), start_k = min(k*B, M-B)
-// (the overlapping tail window of data.rs:121-125).
+// One pass gathers ALL K minibatches: minibatch k is rows [k*B, (k+1)*B) of the output slabs and
+// takes its indices from perm[start_k .. start_k+B), start_k = min(k*B, M-B) (the overlapping
+// tail window of data.rs:121-125).
+//
+// Shape of the kernels (measured with tools/membench*.hip on MI355X, profiles/r1/membench*.log):
+//   * a one-shot grid with ONE 16-byte access per thread and 64-thread workgroups moves random
+//     256-B rows at 6.08 TB/s (95 % of the best streaming copy, 6.4 TB/s); a wave that loops over
+//     64 rows with 4-8 loads in flight per lane reaches only 5.5, and persistent grids are slower
+//     still.  So the observation gather is "thread = one float4 of one output row".
+//   * non-temporal loads AND stores are worth 12 % (each observation byte is touched once).
+//   * the five scalar streams travel as ONE 16-byte record per transition (kernels_gae.h), so a
+//     gathered row costs one random sector, not four.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,26 +26,58 @@
 
 namespace ppoxp {
 
-struct GatherArgs {
-  const float *obs;        // [M, D]
-  const Rec *rec;          // [M]
-  const uint32_t *perm;    // [M]
-  float *obs_out;          // [K*B, D]
-  int64_t *act_out;        // [K*B]
-  float *val_out, *nlp_out, *ret_out, *adv_out;  // [K*B]; adv_out holds RAW adv' until normalize
-  double2 *partials;       // [K * tiles_per_mb] (sum, sum of squares) per 256-row tile
-  size_t M, B;
-  unsigned D, Q, qshift;   // Q = D / V vector elements per row; qshift = log2(Q) if POW2
-  unsigned tiles_per_mb;   // ceil(B / 256)
-};
-
 // native clang vectors (the nontemporal builtins do not take HIP's float4 struct)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct VecT;
 template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = f32x2; };
 template <> struct VecT<4> { using type = f32x4; };
+
+struct ObsGatherArgs {
+  const float *obs;        // [M, D]
+  const uint32_t *perm;    // [M]
+  float *obs_out;          // [K*B, D]
+  size_t M, B, total;      // total = K*B*Q vector elements to move
+  unsigned Q, qshift;      // Q = D / V vector elements per row; qshift = log2(Q) when POW2
+};
+
+// Observation rows.  grid = ceil(K*B*Q / BS) workgroups of BS threads, one vector element each.
+// V = floats per access (4 when D % 4 == 0, else 2 or 1), POW2 = Q is a power of two,
+// TAIL = the last window overlaps (B does not divide M), NT = non-temporal accesses.
+template <int V, int BS, bool NT, bool POW2, bool TAIL>
+__global__ __launch_bounds__(BS) void obs_gather_kernel(ObsGatherArgs g) {
+  using vec = typename VecT<V>::type;
+  const size_t e = (size_t)blockIdx.x * BS + threadIdx.x;     // output vector element
+  if (e >= g.total) return;
+  size_t row; unsigned col;                                   // output row (k*B + r), vector column
+  if (POW2) { row = e >> g.qshift; col = (unsigned)e & (g.Q - 1); }
+  else { row = e / g.Q; col = (unsigned)(e - row * g.Q); }
+  size_t pos = row;                                           // position in the permutation
+  if (TAIL) {                                                 // data.rs:121-122
+    const size_t k = row / g.B, start = k * g.B;
+    if (start + g.B > g.M) pos = row - start + (g.M - g.B);
+  }
+  uint32_t p = g.perm[pos];
+  p = min(p, (uint32_t)(g.M - 1));                            // a bad index can never fault
+  const vec *s = reinterpret_cast<const vec *>(g.obs) + ((size_t)p * g.Q + col);
+  vec *d = reinterpret_cast<vec *>(g.obs_out) + e;
+  if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(s), d);
+  else *d = *s;
+}
+
+struct ScalarGatherArgs {
+  const Rec *rec;          // [M]
+  const int64_t *actions;  // [M] (only read for actions that do not fit the record)
+  const uint32_t *perm;    // [M]
+  int64_t *act_out;        // [K*B]
+  float *val_out, *nlp_out, *ret_out, *adv_out;  // [K*B]; adv_out holds RAW adv' until normalize
+  double2 *partials;       // [K * tiles_per_mb] (sum, sum of squares) per 256-row tile
+  size_t M, B;
+  unsigned tiles_per_mb;   // ceil(B / 256)
+  int rec_nt, out_nt;      // cache policy of the record reads / of the output stores
+};
 
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll
@@ -45,79 +85,48 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
-// grid = K * tiles_per_mb blocks of 256 threads; one wave = 64 consecutive output rows.
-// V = floats per lane access (4 when D % 4 == 0), U = vector loads in flight per lane,
-// NT = non-temporal obs loads/stores (each obs byte is touched once), POW2 = Q is a power of 2.
-template <int V, int U, bool NT, bool POW2>
-__global__ __launch_bounds__(256) void gather_kernel(GatherArgs g) {
-  using vec = typename VecT<V>::type;
+// Scalar streams + advantage statistics.  grid = K * tiles_per_mb workgroups of 256 threads,
+// lane = one output row: one random 16-byte record read, five coalesced stores, and the
+// (sum, sum of squares) of the raw advantages of the tile in fp64.
+__global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) {
   __shared__ double red[4][2];
   const unsigned tile = blockIdx.x;
   const unsigned k = tile / g.tiles_per_mb;
   const unsigned c = tile - k * g.tiles_per_mb;
   const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const size_t r0 = (size_t)c * 256u + w * 64u;               // first row of this wave inside minibatch k
+  const size_t r = (size_t)c * 256u + threadIdx.x;            // row inside minibatch k
   size_t start = (size_t)k * g.B;
   if (start + g.B > g.M) start = g.M - g.B;                   // data.rs:121-122
-  const unsigned rows = r0 < g.B ? (unsigned)min((size_t)64, g.B - r0) : 0u;   // wave-uniform
-  const size_t o0 = (size_t)k * g.B + r0;                     // first output row of this wave
-
-  // ---- scalar streams: lane = row -------------------------------------------------------
-  const bool valid = lane < rows;
-  uint32_t p = 0;
-  float4 lo = make_float4(0.f, 0.f, 0.f, 0.f);
-  longlong2 hi; hi.x = 0; hi.y = 0;
+  const bool valid = r < g.B;
+  float adv = 0.f;
   if (valid) {
-    p = g.perm[start + r0 + lane];
-    p = min(p, (uint32_t)(g.M - 1));                          // never read out of bounds
-    const float4 *src = reinterpret_cast<const float4 *>(g.rec + p);
-    lo = src[0];
-    hi = *reinterpret_cast<const longlong2 *>(src + 1);
-    const size_t o = o0 + lane;
-    g.val_out[o] = lo.x;
-    g.nlp_out[o] = lo.y;
-    g.ret_out[o] = lo.z;
-    g.adv_out[o] = lo.w;                                      // raw; standardised by normalize_kernel
-    g.act_out[o] = hi.x;
-  }
-  // ---- advantage statistics: fp64 partial sums per tile ---------------------------------
-  {
-    double a = valid ? (double)lo.w : 0.0;
-    double s1 = wave_sum(a), s2 = wave_sum(a * a);
-    if (lane == 0) { red[w][0] = s1; red[w][1] = s2; }
-  }
-
-  // ---- observations: the wave's `rows` x D floats are contiguous in the output ----------
-  const unsigned total = rows * g.Q;                          // vector elements of this wave
-  const vec *obs = reinterpret_cast<const vec *>(g.obs);
-  vec *out = reinterpret_cast<vec *>(g.obs_out) + o0 * g.Q;
-  for (unsigned q0 = 0; q0 < total; q0 += 64u * U) {
-    vec buf[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned q = q0 + u * 64u + lane;
-      const unsigned row = POW2 ? (q >> g.qshift) : (q / g.Q);
-      const unsigned col = q - row * g.Q;
-      const uint32_t idx = __shfl(p, (int)(row & 63u), 64);   // all lanes take part
-      if (q < total) {
-        const vec *s = obs + (size_t)idx * g.Q + col;
-        buf[u] = NT ? __builtin_nontemporal_load(s) : *s;
-      }
+    uint32_t p = __builtin_nontemporal_load(g.perm + start + r);
+    p = min(p, (uint32_t)(g.M - 1));
+    const u32x4 *rp = reinterpret_cast<const u32x4 *>(g.rec) + p;
+    const u32x4 q = g.rec_nt ? __builtin_nontemporal_load(rp) : *rp;
+    const float v = __uint_as_float(q.x), nlp = __uint_as_float(q.y), ret = __uint_as_float(q.z);
+    int64_t act = (int64_t)q.w;
+    if (q.w == kRecActEscape) act = g.actions[p];              // rare: action does not fit 32 bits
+    adv = ret - v;                                            // data.rs:62 (same op as the GAE kernel's adv')
+    const size_t o = (size_t)k * g.B + r;
+    if (g.out_nt) {
+      __builtin_nontemporal_store(v, g.val_out + o);
+      __builtin_nontemporal_store(nlp, g.nlp_out + o);
+      __builtin_nontemporal_store(ret, g.ret_out + o);
+      __builtin_nontemporal_store(act, g.act_out + o);
+    } else {
+      g.val_out[o] = v; g.nlp_out[o] = nlp; g.ret_out[o] = ret; g.act_out[o] = act;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned q = q0 + u * 64u + lane;
-      if (q < total) {
-        if (NT) __builtin_nontemporal_store(buf[u], out + q); else out[q] = buf[u];
-      }
-    }
+    g.adv_out[o] = adv;                                       // raw; standardised (re-read) by normalize_kernel
   }
-
+  const double a = valid ? (double)adv : 0.0;
+  const double s1 = wave_sum(a), s2 = wave_sum(a * a);
+  if (lane == 0) { red[w][0] = s1; red[w][1] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double s1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-    double s2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
-    g.partials[tile] = make_double2(s1, s2);
+    const double t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+    const double t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    g.partials[tile] = make_double2(t1, t2);
   }
 }
 
@@ -159,7 +168,8 @@ __device__ __forceinline__ void stats_from_sums(const double *s, float &mean, fl
   stdv = sqrtf(corrected);
 }
 
-// grid = (blocks_x, K), block = 256: in-place standardisation of adv_out[k*B .. (k+1)*B).
+// In-place standardisation of adv_out[k*B .. (k+1)*B).  grid = (ceil(B / 1024), K), block = 256,
+// four consecutive floats per thread (16-byte accesses when the minibatch base allows it).
 __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_out, const double *__restrict__ sums,
                                                         float *__restrict__ stats, size_t B) {
   const unsigned k = blockIdx.y;
@@ -167,8 +177,14 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_
   stats_from_sums(sums + 3 * k, mean, stdv);
   const float denom = stdv + 1e-8f;
   float *a = adv_out + (size_t)k * B;
-  for (size_t j = (size_t)blockIdx.x * 256u + threadIdx.x; j < B; j += (size_t)gridDim.x * 256u)
-    a[j] = (a[j] - mean) / denom;
+  const size_t j = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (j + 4 <= B && ((reinterpret_cast<uintptr_t>(a + j) & 15u) == 0)) {
+    f32x4 x = *reinterpret_cast<f32x4 *>(a + j);
+    x.x = (x.x - mean) / denom; x.y = (x.y - mean) / denom; x.z = (x.z - mean) / denom; x.w = (x.w - mean) / denom;
+    *reinterpret_cast<f32x4 *>(a + j) = x;
+  } else {
+    for (size_t i = j; i < B && i < j + 4; ++i) a[i] = (a[i] - mean) / denom;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) { stats[2 * k] = mean; stats[2 * k + 1] = stdv; }
 }
 

@@ -124,7 +124,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_unroll = 8, gae_unroll = 8, carry_waves = 16;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 8, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1;
 };
 
 namespace {
@@ -192,7 +192,7 @@ int run_gae(ppo_xp *h, int algo) {
   a.rewards = h->rewards; a.values = h->values; a.dones = h->dones; a.neglogps = h->neglogps;
   a.actions = h->actions; a.last_dones = h->last_dones_dev; a.returns = h->returns; a.adv = h->adv;
   a.rec = h->rec; a.N = (unsigned)N; a.len = (unsigned)len; a.lvi = (unsigned)h->last_values_idx;
-  a.gamma = h->gamma;
+  a.gamma = h->gamma; a.nt = (int)h->gae_nt;
   a.gl = h->gamma * h->lambda;  // one fp32 product, computed first (buffer.rs:219)
   unsigned chunks = 1;
   a.chunk = (unsigned)len;
@@ -247,34 +247,44 @@ int run_gae(ppo_xp *h, int algo) {
   return 0;
 }
 
-// ---- gather launch -------------------------------------------------------------------------
-template <int V, int U, bool NT>
-void launch_gather_v(ppo_xp *h, const GatherArgs &g, unsigned blocks, bool pow2) {
-  if (pow2) hipLaunchKernelGGL((gather_kernel<V, U, NT, true>), dim3(blocks), dim3(256), 0, h->stream, g);
-  else hipLaunchKernelGGL((gather_kernel<V, U, NT, false>), dim3(blocks), dim3(256), 0, h->stream, g);
+// ---- gather launches -----------------------------------------------------------------------
+template <int V, int BS, bool NT>
+void launch_obs_v(ppo_xp *h, const ObsGatherArgs &g, unsigned blocks, bool pow2, bool tail) {
+  dim3 grid(blocks), block(BS);
+  if (pow2) {
+    if (tail) hipLaunchKernelGGL((obs_gather_kernel<V, BS, NT, true, true>), grid, block, 0, h->stream, g);
+    else hipLaunchKernelGGL((obs_gather_kernel<V, BS, NT, true, false>), grid, block, 0, h->stream, g);
+  } else {
+    if (tail) hipLaunchKernelGGL((obs_gather_kernel<V, BS, NT, false, true>), grid, block, 0, h->stream, g);
+    else hipLaunchKernelGGL((obs_gather_kernel<V, BS, NT, false, false>), grid, block, 0, h->stream, g);
+  }
 }
 
-int launch_gather(ppo_xp *h, GatherArgs g, unsigned blocks) {
+int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
   const unsigned D = (unsigned)h->D;
   const int V = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-  g.D = D; g.Q = D / V;
-  const bool pow2 = g.Q != 0 && (g.Q & (g.Q - 1)) == 0;
+  ObsGatherArgs g{};
+  g.obs = h->obs; g.perm = h->perm_cur; g.obs_out = h->obs_out; g.M = M; g.B = B;
+  g.Q = D / V;
+  g.total = K * B * g.Q;
+  const bool pow2 = (g.Q & (g.Q - 1)) == 0;
   g.qshift = 0;
   if (pow2) while ((1u << g.qshift) < g.Q) ++g.qshift;
+  const bool tail = K * B != M;
+  const unsigned bs = h->gather_block == 256 ? 256u : 64u;
+  const size_t blocks = (g.total + bs - 1) / bs;
+  if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch (%zu workgroups)", blocks);
   ProfScope ps(h, PPO_XP_K_GATHER);
+  const bool nt = h->gather_nt != 0;
   if (V == 4) {
-    const bool nt = h->gather_nt != 0;
-    switch (h->gather_unroll) {
-      case 4: nt ? launch_gather_v<4, 4, true>(h, g, blocks, pow2) : launch_gather_v<4, 4, false>(h, g, blocks, pow2); break;
-      case 16: nt ? launch_gather_v<4, 16, true>(h, g, blocks, pow2) : launch_gather_v<4, 16, false>(h, g, blocks, pow2); break;
-      default: nt ? launch_gather_v<4, 8, true>(h, g, blocks, pow2) : launch_gather_v<4, 8, false>(h, g, blocks, pow2); break;
-    }
+    if (bs == 64) nt ? launch_obs_v<4, 64, true>(h, g, (unsigned)blocks, pow2, tail) : launch_obs_v<4, 64, false>(h, g, (unsigned)blocks, pow2, tail);
+    else nt ? launch_obs_v<4, 256, true>(h, g, (unsigned)blocks, pow2, tail) : launch_obs_v<4, 256, false>(h, g, (unsigned)blocks, pow2, tail);
   } else if (V == 2) {
-    launch_gather_v<2, 8, false>(h, g, blocks, pow2);
+    if (bs == 64) launch_obs_v<2, 64, true>(h, g, (unsigned)blocks, pow2, tail); else launch_obs_v<2, 256, true>(h, g, (unsigned)blocks, pow2, tail);
   } else {
-    launch_gather_v<1, 8, false>(h, g, blocks, pow2);
+    if (bs == 64) launch_obs_v<1, 64, true>(h, g, (unsigned)blocks, pow2, tail); else launch_obs_v<1, 256, true>(h, g, (unsigned)blocks, pow2, tail);
   }
-  return launch_check("gather_kernel");
+  return launch_check("obs_gather_kernel");
 }
 
 int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
@@ -308,8 +318,9 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
 int pass_finish_impl(ppo_xp *h) {
   const size_t K = h->pass_K, B = h->pass_B;
   if (K == 0) { h->pass_pending_finish = false; return 0; }
-  unsigned bx = (unsigned)std::min<size_t>((B + 1023) / 1024, 4096);
-  bx = std::max(bx, 1u);
+  const size_t nbx = (B + 1023) / 1024;
+  if (nbx > 0x7fffffffull || K > 65535) return fail(PPO_XP_EINVAL, "pass too large for the normalize launch");
+  const unsigned bx = (unsigned)nbx;
   ProfScope ps(h, PPO_XP_K_NORMALIZE);
   hipLaunchKernelGGL(normalize_kernel, dim3(bx, (unsigned)K), dim3(256), 0, h->stream, h->adv_out, h->sums,
                      h->stats, B);
@@ -330,24 +341,33 @@ int pass_begin_impl(ppo_xp *h, size_t B) {
   if (int rc = ensure_pass_buffers(h, K, B)) return rc;
   if (!h->have_rec) {
     ProfScope ps(h, PPO_XP_K_PACK);
-    unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, 8192);
+    unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, 0x7fffffffull);
     hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, h->stream, h->values, h->neglogps,
-                       h->returns, h->adv, h->actions, h->rec, M);
+                       h->returns, h->actions, h->rec, M);
     if (int rc = launch_check("pack_records_kernel")) return rc;
     h->have_rec = true;
   }
-  GatherArgs g{};
-  g.obs = h->obs; g.rec = h->rec; g.perm = h->perm_cur; g.obs_out = h->obs_out; g.act_out = h->act_out;
+  // scalar streams + statistics first (the records were just written by the GAE kernel and are
+  // the most likely bytes to still sit in the Infinity Cache), observation rows after
+  ScalarGatherArgs g{};
+  g.rec = h->rec; g.actions = h->actions; g.perm = h->perm_cur; g.act_out = h->act_out;
   g.val_out = h->val_out; g.nlp_out = h->nlp_out; g.ret_out = h->ret_out; g.adv_out = h->adv_out;
   g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256);
-  const unsigned blocks = (unsigned)(K * g.tiles_per_mb);
-  if (int rc = launch_gather(h, g, blocks)) return rc;
+  g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
+  {
+    ProfScope ps(h, PPO_XP_K_SCALARS);
+    hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
+    if (int rc = launch_check("scalar_gather_kernel")) return rc;
+  }
   {
     ProfScope ps(h, PPO_XP_K_FINALIZE);
     hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
                        g.tiles_per_mb, B);
     if (int rc = launch_check("finalize_stats_kernel")) return rc;
   }
+  // the observation rows do not depend on the statistics: enqueue them before the exchange so
+  // that the all-reduce's host-side latency hides behind ~0.7 ms of GPU work
+  if (int rc = launch_obs_gather(h, K, B, M)) return rc;
   if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
   if (h->xmode == 1) {
     int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
@@ -368,7 +388,7 @@ const char *ppo_xp_version(void) { return "ppo_xp 0.1 (gfx950)"; }
 
 const char *ppo_xp_kernel_name(int k) {
   static const char *names[PPO_XP_K_COUNT] = {"gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records",
-                                              "gather", "finalize_stats", "normalize"};
+                                              "gather", "finalize_stats", "normalize", "scalar_gather"};
   return (k >= 0 && k < PPO_XP_K_COUNT) ? names[k] : "?";
 }
 
@@ -711,7 +731,10 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   if (!h || !name) return fail(PPO_XP_EINVAL, "set_tunable: NULL argument");
   std::string n(name);
   if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
-  else if (n == "gather_unroll" && (value == 4 || value == 8 || value == 16)) h->gather_unroll = value;
+  else if (n == "gather_block" && (value == 64 || value == 256)) h->gather_block = value;
+  else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
+  else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
+  else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 4 || value == 8 || value == 16)) h->gae_unroll = value;
   else if (n == "carry_waves" && (value == 4 || value == 8 || value == 16)) h->carry_waves = value;
   else return fail(PPO_XP_EINVAL, "set_tunable: unknown name or bad value: %s = %ld", name, value);

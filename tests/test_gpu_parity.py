@@ -273,6 +273,9 @@ def test_large_actions_are_kept(xp, oracle):
     r = synth.rollout(4, 6, 2, 51, 0.0)
     r["actions"][1, 2] = np.uint64(2**40 + 7)
     r["actions"][3, 5] = np.uint64(2**63 - 1)
+    r["actions"][0, 0] = np.uint64(0xFFFFFFFF)      # equals the record's escape value
+    r["actions"][2, 1] = np.uint64(0xFFFFFFFE)      # largest value kept inside the record
+    r["actions"][2, 4] = np.uint64(2**32)
     g = xp.ExperienceBuffer(6, 2, 4)
     fill(g, r)
     g.returns(r["last_dones"])

@@ -17,7 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="TGT")
     ap.add_argument("--rounds", type=int, default=7)
-    ap.add_argument("--grid", default="gather_nt=0,1;gather_unroll=4,8,16")
+    ap.add_argument("--grid", default="gather_nt=0,1;gather_block=64,256")
     ap.add_argument("--kernel", default="gather")
     ap.add_argument("--algo", type=int, default=0)
     args = ap.parse_args()
