@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
     ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
     import torch
@@ -175,7 +176,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    buf.prof_enable(True)
+    buf.prof_enable(not args.no_kernel_events)
     buf.prof_collect()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -41,7 +41,26 @@ struct ObsGatherArgs {
   float *obs_out;          // [K*B, D]
   size_t M, B, total;      // total = K*B*Q vector elements to move
   unsigned Q, qshift;      // Q = D / V vector elements per row; qshift = log2(Q) when POW2
+  unsigned nblocks, xcd;   // grid size; xcd: 0 = identity, 1 = 8x8 chunk remap, 2 = one contiguous eighth per XCD
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the L2 a block uses) and
+// one 128-byte line of the permutation feeds 32 rows = several 64-thread workgroups.  Unmapped,
+// those workgroups sit on 8 different L2s and each fetches the line again (measured: 2.1 M extra
+// 128-B reads per pass, profiles/r1/pmc_TGT_v2_split_gather.txt).  The remaps make workgroups
+// that share an XCD work on consecutive tiles.  Both are bijections on [0, nblocks).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks, unsigned mode) {
+  if (mode == 1) {                       // inside every aligned group of 64 workgroups: XCD x takes tiles 8x..8x+7
+    const unsigned base = b & ~63u;
+    if (base + 64u > nblocks) return b;  // ragged last group stays as it is
+    return base + ((b & 7u) << 3) + ((b >> 3) & 7u);
+  }
+  if (mode == 2) {                       // XCD x streams through its own contiguous eighth of the tiles
+    const unsigned q = nblocks >> 3, r = nblocks & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+  }
+  return b;
+}
 
 // Observation rows.  grid = ceil(K*B*Q / BS) workgroups of BS threads, one vector element each.
 // V = floats per access (4 when D % 4 == 0, else 2 or 1), POW2 = Q is a power of two,
@@ -49,7 +68,7 @@ struct ObsGatherArgs {
 template <int V, int BS, bool NT, bool POW2, bool TAIL>
 __global__ __launch_bounds__(BS) void obs_gather_kernel(ObsGatherArgs g) {
   using vec = typename VecT<V>::type;
-  const size_t e = (size_t)blockIdx.x * BS + threadIdx.x;     // output vector element
+  const size_t e = (size_t)xcd_remap(blockIdx.x, g.nblocks, g.xcd) * BS + threadIdx.x;   // output vector element
   if (e >= g.total) return;
   size_t row; unsigned col;                                   // output row (k*B + r), vector column
   if (POW2) { row = e >> g.qshift; col = (unsigned)e & (g.Q - 1); }

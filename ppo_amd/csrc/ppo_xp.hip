@@ -124,7 +124,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 8, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 8, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0;
 };
 
 namespace {
@@ -274,6 +274,7 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
   const unsigned bs = h->gather_block == 256 ? 256u : 64u;
   const size_t blocks = (g.total + bs - 1) / bs;
   if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch (%zu workgroups)", blocks);
+  g.nblocks = (unsigned)blocks; g.xcd = (unsigned)h->gather_xcd;
   ProfScope ps(h, PPO_XP_K_GATHER);
   const bool nt = h->gather_nt != 0;
   if (V == 4) {
@@ -365,14 +366,17 @@ int pass_begin_impl(ppo_xp *h, size_t B) {
                        g.tiles_per_mb, B);
     if (int rc = launch_check("finalize_stats_kernel")) return rc;
   }
-  // the observation rows do not depend on the statistics: enqueue them before the exchange so
-  // that the all-reduce's host-side latency hides behind ~0.7 ms of GPU work
+  if (h->xmode == 0) {
+    // single GPU: standardise while the raw advantages are still in L2 / Infinity Cache, rows last
+    if (int rc = pass_finish_impl(h)) return rc;
+    return launch_obs_gather(h, K, B, M);
+  }
+  // sharded: the observation rows do not depend on the statistics; enqueue them before the
+  // exchange so that the all-reduce's host-side latency hides behind ~0.7 ms of GPU work
   if (int rc = launch_obs_gather(h, K, B, M)) return rc;
   if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
-  if (h->xmode == 1) {
-    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
-    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
-  }
+  int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
   return pass_finish_impl(h);
 }
 
@@ -732,6 +736,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   std::string n(name);
   if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
   else if (n == "gather_block" && (value == 64 || value == 256)) h->gather_block = value;
+  else if (n == "gather_xcd" && value >= 0 && value <= 2) h->gather_xcd = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
