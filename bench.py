@@ -32,8 +32,11 @@ def alg_bytes_total(D):      # B_alg = 8D + 2A + I + 56
     return 8 * D + 2 * ACTION_BYTES + INDEX_BYTES + 56
 
 
-def alg_bytes_gather(D):     # gather row of 8(d): obs 8D + actions 2A + 24 + adv 8 + index I
-    return 8 * D + 2 * ACTION_BYTES + 24 + 8 + INDEX_BYTES
+# How B_alg splits over the kernels (DESIGN.md "Kernels"): GAE 20 | scalar gather: index I +
+# actions 2A + values/neglogps/returns 24 + advantage reads 8 | normalize: standardised write 4 |
+# observation gather: 8D.
+def alg_bytes_obs_gather(D):
+    return 8 * D
 
 
 def log(*a):
@@ -176,7 +179,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     barrier()
-    buf.prof_enable(not args.no_kernel_events)
+    # timed region: HIP events only around the dominant kernel (an event pair costs ~7 us of stream time)
+    buf.prof_enable(False if args.no_kernel_events else ["gather"])
     buf.prof_collect()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -184,6 +188,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof = buf.prof_collect()
+    # per-kernel breakdown: a few more steps with every kernel bracketed, outside the timed region
+    buf.prof_enable(True)
+    for i in range(5):
+        step(i)
+    barrier()
+    prof_all = buf.prof_collect()
     buf.prof_enable(False)
 
     if world > 1:
@@ -196,8 +206,8 @@ def main():
         value = world * M * args.steps / dt
         g_ms, g_n = prof["gather"]
         g_avg_s = g_ms / max(g_n, 1) * 1e-3
-        achieved = M * alg_bytes_gather(D) / g_avg_s / 1e9 if g_n else 0.0
-        kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof.items() if v[1]}
+        achieved = M * alg_bytes_obs_gather(D) / g_avg_s / 1e9 if g_n else 0.0
+        kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
         out = {
             "metric": "transitions/sec through GAE+norm+minibatch gather", "value": value, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -206,19 +216,20 @@ def main():
                                    "gamma=0.99 lambda=0.95, sequential GAE scan + one shuffled pass",
                        "global_envs": world * N, "parallelism": f"env-sharded x{world}" if world > 1 else "single GPU",
                        "exchange": (args.exchange if world > 1 else "none")},
-            "hbm_roofline_frac_whole_step": world * M * alg_bytes_total(D) / dt * args.steps / (world * HBM_PEAK_GBS * 1e9),
+            "hbm_roofline_frac_whole_step": value * alg_bytes_total(D) / (world * HBM_PEAK_GBS * 1e9),
             "alg_bytes_per_transition": alg_bytes_total(D),
-            "roofline": {"bound": "hbm", "kernel": "gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "obs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "alg_bytes_per_launch": M * alg_bytes_gather(D), "avg_launch_us": g_avg_s * 1e6},
-            "kernels": kern,
+                         "alg_bytes_per_launch": M * alg_bytes_obs_gather(D), "avg_launch_us": g_avg_s * 1e6,
+                         "launches_timed": g_n},
+            "kernels_untimed_breakdown": kern,
             "off_metric": {"insert_s": t_insert, "perm_host_fisher_yates_s": t_perm},
         }
         traffic_file = os.path.join(ROOT, "profiles", "gather_traffic.json")
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                if tf.get("config") == args.config:
+                if tf.get("config") == args.config and tf.get("kernel") == "obs_gather_kernel":
                     out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tf.get("source")
             except Exception:

@@ -186,8 +186,9 @@ int ppo_xp_sync(ppo_xp *h);                      /* hipStreamSynchronize        
 int ppo_xp_device(const ppo_xp *h);
 
 /* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline numbers).
- * enable != 0 starts recording an event pair around every kernel launch; collect
- * synchronises, adds up elapsed ms and launch counts per kernel id and resets. */
+ * enable: 0 = off, -1 = every kernel, otherwise a bit mask (bit k = kernel id k).  While on, an
+ * event pair is recorded around every launch of the selected kernels; collect synchronises, adds
+ * up elapsed ms and launch counts per kernel id and resets. */
 enum { PPO_XP_K_GAE = 0, PPO_XP_K_GAE_SUMMARY, PPO_XP_K_GAE_CARRY, PPO_XP_K_PACK, PPO_XP_K_GATHER,
        PPO_XP_K_FINALIZE, PPO_XP_K_NORMALIZE, PPO_XP_K_SCALARS, PPO_XP_K_COUNT };
 int ppo_xp_prof_enable(ppo_xp *h, int enable);

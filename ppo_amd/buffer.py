@@ -235,7 +235,14 @@ class ExperienceBuffer:
         check(self._L.ppo_xp_set_tunable(self._h, name.encode(), int(value)))
 
     def prof_enable(self, on=True):
-        check(self._L.ppo_xp_prof_enable(self._h, 1 if on else 0))
+        """True / False, or an iterable of kernel names (see _lib.K_NAMES) to time only those."""
+        if on is True:
+            mask = -1
+        elif not on:
+            mask = 0
+        else:
+            mask = sum(1 << _lib.K_NAMES.index(n) for n in on)
+        check(self._L.ppo_xp_prof_enable(self._h, mask))
 
     def prof_collect(self):
         """{kernel name: (total ms, launches)} since the last collect (synchronises)."""

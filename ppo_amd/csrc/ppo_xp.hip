@@ -120,7 +120,7 @@ struct ppo_xp {
   int xmode = 0; void *comm = nullptr;
   // stream / profiling
   hipStream_t stream = nullptr; bool own_stream = false;
-  bool prof = false;
+  unsigned prof = 0;   // bit k set: record an event pair around every launch of kernel id k
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
@@ -134,12 +134,12 @@ size_t buf_len(const ppo_xp *h) { return h->counter >= h->capacity ? h->capacity
 struct ProfScope {
   ppo_xp *h; int kid; hipEvent_t a = nullptr, b = nullptr;
   ProfScope(ppo_xp *h_, int kid_) : h(h_), kid(kid_) {
-    if (!h->prof) return;
+    if (!((h->prof >> kid) & 1u)) return;
     a = take(); b = take();
     if (a && b) (void)hipEventRecord(a, h->stream);
   }
   ~ProfScope() {
-    if (!h->prof || !a || !b) return;
+    if (!a || !b) return;
     (void)hipEventRecord(b, h->stream);
     h->prof_recs.push_back({kid, a, b});
   }
@@ -713,7 +713,7 @@ int ppo_xp_device(const ppo_xp *h) { return h ? h->device : -1; }
 
 int ppo_xp_prof_enable(ppo_xp *h, int enable) {
   if (!h) return fail(PPO_XP_EINVAL, "prof_enable: handle is NULL");
-  h->prof = enable != 0;
+  h->prof = enable < 0 ? 0xffffffffu : (unsigned)enable;
   return 0;
 }
 
