@@ -128,6 +128,11 @@ size_t ppo_xp_last_values_idx(const ppo_xp *h);
  * returns to it (synchronises).  n != num_envs => PPO_XP_EINVAL (buffer.rs:194). */
 int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out);
 
+/* explained_variance(values, returns) of train() (ppo/src/training.rs:88-99, called at :189):
+ * 0 - var(returns - values) / var(returns), population variances (fp64 sums on the device; the
+ * reference runs ndarray's sequential fp32 Welford).  Needs ppo_xp_returns() first; synchronises. */
+int ppo_xp_explained_variance(ppo_xp *h, float *out);
+
 /* ExperienceBuffer::training_views (buffer.rs:142-175) + the batcher's master set. */
 int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out);
 
@@ -149,6 +154,10 @@ int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64
  * pass_begin).  Entries are not range-checked; the kernel clamps them to M-1 so that a bad index
  * can never fault the GPU. */
 int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_dev);
+/* Same, with the permutation drawn ON THE DEVICE (no host Fisher-Yates, no upload): perm = stable
+ * argsort of key_i = SplitMix64(seed, i).  A uniform permutation like the reference's, but NOT the
+ * sequence rand's shuffle would give for this seed; reproducible, with a CPU twin in the oracle. */
+int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed);
 /* Iterator::next (data.rs:115-192): 0 = *out filled, 1 = exhausted (`None`), < 0 error.
  * The windows follow data.rs:121-126 exactly, including the overlapping tail batch. */
 int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out);

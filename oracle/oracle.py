@@ -71,6 +71,14 @@ def lib() -> C.CDLL:
         L.orc_shuffle.argtypes = [u64, sz, vp]
         L.orc_run_path.restype = i32
         L.orc_run_path.argtypes = [vp] * 6 + [sz, sz, sz, sz, vp, f32, f32, vp, sz] + [vp] * 8 + [i32]
+        L.orc_keyed_shuffle.restype = i32
+        L.orc_keyed_shuffle.argtypes = [u64, sz, vp]
+        L.orc_var_welford_f32.restype = f32
+        L.orc_var_welford_f32.argtypes = [vp, sz, f32]
+        L.orc_explained_variance.restype = f32
+        L.orc_explained_variance.argtypes = [vp, vp, sz]
+        L.orc_explained_variance_f64.restype = C.c_double
+        L.orc_explained_variance_f64.argtypes = [vp, vp, sz]
         L.orc_max_threads.restype = i32
         _lib = L
     return _lib
@@ -265,6 +273,34 @@ def shuffle(seed, M):
     rc = lib().orc_shuffle(seed, M, _p(out))
     assert rc == 0
     return out
+
+
+def keyed_shuffle(seed, M):
+    """CPU twin of the device permutation generator: stable argsort of SplitMix64(seed, i)."""
+    out = np.empty(M, np.uint32)
+    assert lib().orc_keyed_shuffle(seed, M, _p(out)) == 0
+    return out
+
+
+def np_keyed_shuffle(seed, M):
+    """Independent numpy restatement of keyed_shuffle."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + (np.arange(M, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return np.argsort(z, kind="stable").astype(np.uint32)
+
+
+def explained_variance(values, returns):
+    """training.rs:88-99 with ndarray's sequential fp32 Welford variance."""
+    values, returns = _c(values, np.float32), _c(returns, np.float32)
+    return lib().orc_explained_variance(_p(values), _p(returns), values.size)
+
+
+def explained_variance_f64(values, returns):
+    values, returns = _c(values, np.float32), _c(returns, np.float32)
+    return lib().orc_explained_variance_f64(_p(values), _p(returns), values.size)
 
 
 def run_pass(streams, T, N, D, last_values_idx, last_dones, gamma, lam, perm, B, nthreads=1, outs=None):

@@ -418,3 +418,77 @@ int orc_max_threads(void) {
   return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Next rows                                                             */
+/* ------------------------------------------------------------------------------------ */
+
+/* CPU twin of the DEVICE permutation generator (not in the reference, whose shuffle is the host
+ * Fisher-Yates above): key_i = i-th output of SplitMix64 started at `seed`; perm = stable argsort.
+ * Implemented as an LSD radix sort on (key, index) so that ties keep index order. */
+static uint64_t orc_splitmix64_at(uint64_t seed, uint64_t i) {
+  uint64_t z = seed + (i + 1) * 0x9E3779B97F4A7C15ULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+
+int orc_keyed_shuffle(uint64_t seed, size_t M, uint32_t *indices) {
+  if (M > 0xFFFFFFFFull) return -1;
+  uint64_t *k0 = (uint64_t *)malloc((M ? M : 1) * 8), *k1 = (uint64_t *)malloc((M ? M : 1) * 8);
+  uint32_t *v0 = (uint32_t *)malloc((M ? M : 1) * 4), *v1 = (uint32_t *)malloc((M ? M : 1) * 4);
+  for (size_t i = 0; i < M; ++i) { k0[i] = orc_splitmix64_at(seed, i); v0[i] = (uint32_t)i; }
+  for (int pass = 0; pass < 4; ++pass) {
+    size_t *cnt = (size_t *)calloc(65537, sizeof(size_t));
+    const int sh = 16 * pass;
+    for (size_t i = 0; i < M; ++i) cnt[((k0[i] >> sh) & 0xFFFF) + 1]++;
+    for (size_t b = 0; b < 65536; ++b) cnt[b + 1] += cnt[b];
+    for (size_t i = 0; i < M; ++i) { size_t d = cnt[(k0[i] >> sh) & 0xFFFF]++; k1[d] = k0[i]; v1[d] = v0[i]; }
+    free(cnt);
+    uint64_t *tk = k0; k0 = k1; k1 = tk;
+    uint32_t *tv = v0; v0 = v1; v1 = tv;
+  }
+  memcpy(indices, v0, M * 4);
+  free(k0); free(k1); free(v0); free(v1);
+  return 0;
+}
+
+/* ndarray 0.15.6 `var_axis(Axis(0), ddof)` on a 1-D f32 array (used by explained_variance,
+ * ppo/src/training.rs:91,96): sequential Welford with a fused multiply-add,
+ *   delta = x - mean; mean += delta / count; sum_sq = (x - mean).mul_add(delta, sum_sq); -> sum_sq / (n - ddof).
+ * ndarray is not on disk: restated from the published crate source, PARITY UNPINNED. */
+float orc_var_welford_f32(const float *x, size_t n, float ddof) {
+  float mean = 0.0f, sum_sq = 0.0f;
+  for (size_t i = 0; i < n; ++i) {
+    const float count = (float)(i + 1);
+    const float delta = x[i] - mean;
+    mean = mean + delta / count;
+    sum_sq = fmaf(x[i] - mean, delta, sum_sq);
+  }
+  return sum_sq / ((float)n - ddof);
+}
+
+/* explained_variance — ppo/src/training.rs:88-99 (predictions = values, targets = returns).
+ * Note `0.0 -`, not `1.0 -`, and the guard against -1.0: reproduced as written. */
+float orc_explained_variance(const float *values, const float *returns, size_t n) {
+  const float target_variance = orc_var_welford_f32(returns, n, 0.0f);     /* training.rs:91 */
+  if (target_variance == -1.0f) return NAN;                                 /* training.rs:92 */
+  float *diff = (float *)malloc((n ? n : 1) * sizeof(float));
+  for (size_t i = 0; i < n; ++i) diff[i] = returns[i] - values[i];         /* training.rs:95 */
+  const float diff_variance = orc_var_welford_f32(diff, n, 0.0f);          /* training.rs:96 */
+  free(diff);
+  return 0.0f - (diff_variance / target_variance);                          /* training.rs:97 */
+}
+
+/* fp64 companion (NOT the reference). */
+double orc_explained_variance_f64(const float *values, const float *returns, size_t n) {
+  long double sr = 0, sd = 0;
+  for (size_t i = 0; i < n; ++i) { sr += returns[i]; sd += (double)(returns[i] - values[i]); }
+  const long double mr = sr / n, md = sd / n;
+  long double qr = 0, qd = 0;
+  for (size_t i = 0; i < n; ++i) {
+    long double a = returns[i] - mr, b = (double)(returns[i] - values[i]) - md;
+    qr += a * a; qd += b * b;
+  }
+  return (double)(0.0L - (qd / n) / (qr / n));
+}

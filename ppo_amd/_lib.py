@@ -65,6 +65,8 @@ SYMBOLS = {
     "ppo_xp_views": (_i, [_vp, C.POINTER(ViewsT)]),
     "ppo_xp_pass_begin": (_i, [_vp, _sz, _vp, _u64]),
     "ppo_xp_pass_begin_device": (_i, [_vp, _sz, _vp]),
+    "ppo_xp_pass_begin_device_shuffle": (_i, [_vp, _sz, _u64]),
+    "ppo_xp_explained_variance": (_i, [_vp, C.POINTER(C.c_float)]),
     "ppo_xp_pass_next": (_i, [_vp, C.POINTER(BatchView)]),
     "ppo_xp_pass_num_batches": (_sz, [_vp]),
     "ppo_xp_pass_perm_device": (_vp, [_vp]),

@@ -186,6 +186,12 @@ class ExperienceBuffer:
         self.sync()
         return device_tensor(self._views().returns, (M,), torch.float32, self.device, self)
 
+    def explained_variance(self) -> float:
+        """explained_variance(values, returns) of train() (training.rs:88-99), after returns()."""
+        out = C.c_float()
+        check(self._L.ppo_xp_explained_variance(self._h, C.byref(out)))
+        return out.value
+
     def advantages(self):
         """`returns - values` of ExperienceBatcher::new (data.rs:62), device view [M]."""
         import torch

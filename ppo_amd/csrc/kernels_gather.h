@@ -207,4 +207,25 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_
   if (blockIdx.x == 0 && threadIdx.x == 0) { stats[2 * k] = mean; stats[2 * k + 1] = stdv; }
 }
 
+// explained_variance (ppo/src/training.rs:88-99) needs var(returns) and var(returns - values), both
+// with ddof 0.  One pass: fp64 (sum, sum of squares) of both streams per block -> partials[block]
+// = (S_ret, Q_ret, S_adv, Q_adv); the host adds the few thousand partials in block order.
+__global__ __launch_bounds__(256) void moments_kernel(const float *__restrict__ ret, const float *__restrict__ adv,
+                                                      size_t M, double *__restrict__ partials) {
+  __shared__ double red[4][4];
+  double s[4] = {0.0, 0.0, 0.0, 0.0};
+  for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < M; i += (size_t)gridDim.x * 256u) {
+    const double r = ret[i], a = adv[i];
+    s[0] += r; s[1] += r * r; s[2] += a; s[3] += a * a;
+  }
+  const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { s[k] = wave_sum(s[k]); if (lane == 0) red[w][k] = s[k]; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const unsigned k = threadIdx.x;
+    partials[4 * (size_t)blockIdx.x + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+  }
+}
+
 }  // namespace ppoxp

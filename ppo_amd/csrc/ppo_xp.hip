@@ -19,6 +19,7 @@
 #include "kernels_gae.h"
 #include "kernels_gather.h"
 #include "shuffle.h"
+#include "device_shuffle.h"
 
 using namespace ppoxp;
 
@@ -116,6 +117,8 @@ struct ppo_xp {
   size_t pass_B = 0, pass_K = 0, pass_M = 0, pass_iter = 0;
   bool pass_active = false, pass_pending_finish = false;
   std::vector<uint32_t> perm_host;
+  void *shuffle_ws = nullptr; size_t shuffle_ws_bytes = 0;   // device permutation generator workspace
+  double *moments = nullptr;                                  // [kMomentBlocks][4] partials of explained_variance
   // exchange
   int xmode = 0; void *comm = nullptr;
   // stream / profiling
@@ -156,7 +159,12 @@ int dev_alloc(T **p, size_t count, bool zero) {
   *p = nullptr;
   size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
   HIP_TRY(hipMalloc((void **)p, bytes));
-  if (zero) HIP_TRY(hipMemset(*p, 0, bytes));
+  if (zero) {
+    // hipMemset runs on the NULL stream, which a non-blocking handle stream does not wait for:
+    // finish it here, or it could land after a kernel of the handle has already written the buffer
+    HIP_TRY(hipMemset(*p, 0, bytes));
+    HIP_TRY(hipDeviceSynchronize());
+  }
   return 0;
 }
 
@@ -456,6 +464,8 @@ void ppo_xp_destroy(ppo_xp *h) {
   dev_free(h->last_dones_dev); dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
   dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out);
   dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
+  dev_free(h->moments);
+  if (h->shuffle_ws) { (void)hipFree(h->shuffle_ws); h->shuffle_ws = nullptr; }
   if (h->last_dones_pin) (void)hipHostFree(h->last_dones_pin);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -597,6 +607,52 @@ int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_
   HIP_TRY(hipSetDevice(h->device));
   h->perm_cur = perm_dev;  // borrowed, not copied: see include/ppo_xp.h
   return pass_begin_impl(h, batch_size);
+}
+
+int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed) {
+  if (!h) return fail(PPO_XP_EINVAL, "pass_begin: handle is NULL");
+  if (batch_size == 0) return fail(PPO_XP_EINVAL, "pass_begin: batch_size 0 (the reference would iterate forever)");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t M = buf_len(h) * h->N;
+  if (M) {
+    const size_t need = device_shuffle_workspace_bytes(M);
+    if (need > h->shuffle_ws_bytes) {
+      if (h->shuffle_ws) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipFree(h->shuffle_ws); h->shuffle_ws = nullptr; h->shuffle_ws_bytes = 0; }
+      HIP_TRY(hipMalloc(&h->shuffle_ws, need));
+      h->shuffle_ws_bytes = need;
+    }
+    int e = device_shuffle(seed, M, h->perm, h->shuffle_ws, h->shuffle_ws_bytes, h->stream);
+    if (e != 0) return fail(PPO_XP_EIO, "device shuffle failed: %s", hipGetErrorString((hipError_t)e));
+  }
+  h->perm_cur = h->perm;
+  return pass_begin_impl(h, batch_size);
+}
+
+// explained_variance (training.rs:88-99): 0 - var(returns - values) / var(returns), ddof 0; the
+// reference's guard compares the target variance with -1.0 (never true) and is kept as it is.
+int ppo_xp_explained_variance(ppo_xp *h, float *out) {
+  if (!h || !out) return fail(PPO_XP_EINVAL, "explained_variance: NULL argument");
+  const size_t len = buf_len(h), M = len * h->N;
+  if (!h->have_returns || h->ret_len != len) return fail(PPO_XP_ESTATE, "explained_variance: call ppo_xp_returns() first");
+  HIP_TRY(hipSetDevice(h->device));
+  constexpr unsigned kBlocks = 2048;
+  if (!h->moments) { if (int rc = dev_alloc(&h->moments, 4 * (size_t)kBlocks, true)) return rc; }
+  if (M == 0) { *out = __builtin_nanf(""); return 0; }        // var of nothing = 0/0
+  hipLaunchKernelGGL(moments_kernel, dim3(kBlocks), dim3(256), 0, h->stream, h->returns, h->adv, M, h->moments);
+  if (int rc = launch_check("moments_kernel")) return rc;
+  std::vector<double> part(4 * (size_t)kBlocks);
+  HIP_TRY(hipMemcpyAsync(part.data(), h->moments, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  double s[4] = {0, 0, 0, 0};
+  for (unsigned b = 0; b < kBlocks; ++b) for (int k = 0; k < 4; ++k) s[k] += part[4 * (size_t)b + k];
+  const double n = (double)M;
+  const double mr = s[0] / n, ma = s[2] / n;
+  double vr = (s[1] - s[0] * mr) / n, va = (s[3] - s[2] * ma) / n;
+  if (vr < 0) vr = 0; if (va < 0) va = 0;
+  const float target_variance = (float)vr, diff_variance = (float)va;
+  if (target_variance == -1.0f) *out = __builtin_nanf("");        // training.rs:92 (sic)
+  else *out = 0.0f - (diff_variance / target_variance);           // training.rs:97
+  return 0;
 }
 
 int ppo_xp_pass_finish(ppo_xp *h) {

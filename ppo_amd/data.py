@@ -66,16 +66,17 @@ class ExperienceBatcher:
     def __iter__(self):
         return self.into_iter()
 
-    def into_iter(self, seed: int | None = None, perm=None):
+    def into_iter(self, seed: int | None = None, perm=None, device_shuffle: bool = False):
         """data.rs:91-102: a fresh permutation per pass.  perm: optional host u32 array or CUDA
-        int32 tensor of M indices."""
-        return ExperienceBatcherIterator(self, seed, perm)
+        int32 tensor of M indices.  device_shuffle=True draws the permutation on the GPU (stable
+        argsort of SplitMix64 keys) instead of the host Fisher-Yates."""
+        return ExperienceBatcherIterator(self, seed, perm, device_shuffle)
 
 
 class ExperienceBatcherIterator:
     """data.rs:105-193."""
 
-    def __init__(self, batcher: ExperienceBatcher, seed=None, perm=None):
+    def __init__(self, batcher: ExperienceBatcher, seed=None, perm=None, device_shuffle=False):
         self.batcher = batcher
         buf, L = batcher.buffer, batcher._L
         h = buf.handle
@@ -96,7 +97,10 @@ class ExperienceBatcherIterator:
                 seed = batcher._seed if batcher._seed is not None else next(ExperienceBatcher._seed_counter)
                 if batcher._seed is not None:
                     batcher._seed += 1  # a new permutation per pass (training.rs:204-205)
-            check(L.ppo_xp_pass_begin(h, B, None, int(seed) & 0xFFFFFFFFFFFFFFFF))
+            if device_shuffle:
+                check(L.ppo_xp_pass_begin_device_shuffle(h, B, int(seed) & 0xFFFFFFFFFFFFFFFF))
+            else:
+                check(L.ppo_xp_pass_begin(h, B, None, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
     def __iter__(self):
         return self

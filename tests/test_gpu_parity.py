@@ -357,3 +357,38 @@ def test_panics(xp):
     with pytest.raises(xp.PpoXpError):
         xp.ExperienceBuffer(0, 3, 3)
     buf.close()
+
+
+# ---- next rows ---------------------------------------------------------------
+
+@pytest.mark.parametrize("M_shape,B", [((7, 3, 2), 5), ((40, 96, 8), 1000), ((128, 4096, 4), 65536)])
+def test_device_shuffle_matches_cpu_twin(xp, oracle, M_shape, B):
+    """Device permutation generator: indices bit-exact against the oracle's twin, and the pass that
+    uses them gathers source[perm]."""
+    from ppo_amd import synth
+    T, N, D = M_shape
+    r = synth.rollout(T, N, D, 5, 0.05)
+    g = xp.ExperienceBuffer(N, D, T)
+    g.add_many(r["obs"], r["rewards"], r["actions"], r["values"], r["dones"], r["neglogps"])
+    g.returns(r["last_dones"])
+    for seed in (1, 2**63 + 12345):
+        it = xp.ExperienceBatcher(g, B).into_iter(seed=seed, device_shuffle=True)
+        p = it.perm()
+        np.testing.assert_array_equal(p, oracle.keyed_shuffle(seed, T * N))
+        obs = r["obs"].reshape(T * N, D)
+        for (s, e), b in zip(oracle.batch_windows(T * N, B), it):
+            np.testing.assert_array_equal(bits(b.observations.cpu().numpy()), bits(obs[p[s:e]]))
+    g.close()
+
+
+@pytest.mark.parametrize("T,N", [(3, 2), (128, 8), (64, 1000)])
+def test_explained_variance(xp, oracle, T, N):
+    """training.rs:88-99.  Reduction order of ndarray's Welford is unpinned: tolerance 2e-5 against
+    the fp32 restatement, 2e-6 against fp64."""
+    g, o, r = both(xp, oracle, T, N, 2, T, seed=91 + N, bulk=True)
+    ret = g.returns(r["last_dones"], to_host=True)
+    ev = g.explained_variance()
+    _, _, val, _ = o.training_views()
+    assert abs(ev - oracle.explained_variance_f64(val, ret)) < 2e-6 * max(1.0, abs(ev))
+    assert abs(ev - oracle.explained_variance(val, ret)) < 2e-5 * max(1.0, abs(ev))
+    g.close()

@@ -181,3 +181,24 @@ def test_golden_fixtures_match_oracle(oracle):
     out = oracle.run_pass(streams, T, N, D, T - 1, z["last_dones"], 0.99, 0.95, perm, B)
     for k in ("returns", "adv", "obs", "actions", "values", "neglogps", "ret", "advn"):
         np.testing.assert_array_equal(out[k].view(np.uint8), z["out_" + k].view(np.uint8), err_msg=k)
+
+
+def test_keyed_shuffle_twins_agree(oracle):
+    for M in (0, 1, 2, 1000, 70001):
+        a, b = oracle.keyed_shuffle(99, M), oracle.np_keyed_shuffle(99, M)
+        np.testing.assert_array_equal(a, b)
+        assert np.array_equal(np.sort(a), np.arange(M, dtype=np.uint32))
+    assert not np.array_equal(oracle.keyed_shuffle(1, 1000), oracle.keyed_shuffle(2, 1000))
+
+
+def test_explained_variance_restatement(oracle):
+    g = np.random.default_rng(3)
+    ret = g.standard_normal(5000).astype(np.float32) * 2 + 1
+    val = ret + g.standard_normal(5000).astype(np.float32) * 0.5
+    ev = oracle.explained_variance(val, ret)
+    ev64 = oracle.explained_variance_f64(val, ret)
+    assert abs(ev - ev64) < 1e-5
+    # training.rs:97 is `0.0 - ratio` (not `1.0 - ratio`): a perfect predictor scores -0.0, not 1.0
+    assert oracle.explained_variance(ret, ret) == 0.0
+    want = -np.var((ret - val).astype(np.float64)) / np.var(ret.astype(np.float64))
+    assert abs(ev64 - want) < 1e-9
