@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--config", default="TGT", help="TGT | C2 | C3 (per-GPU shard of the workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
+    ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank control flow with all ranks on one GPU")
     ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -96,14 +98,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
+    if args.backend == "gloo":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     import ppo_amd
-    from ppo_amd import _lib, synth
+    from ppo_amd import _lib, sharded, synth
 
     T, N, D, B = synth.CONFIGS[args.config]   # per-GPU shard: weak scaling, every rank owns N envs
     M = T * N
@@ -150,21 +157,20 @@ def main():
                 raw = (C.c_char * 128)()
                 _lib.check(L.ppo_xp_rccl_unique_id(raw))
                 uid = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
-            uid = uid.to(dev)
+            uid = uid.to(dev) if args.backend == "nccl" else uid
             dist.broadcast(uid, 0)
             raw = (C.c_char * 128).from_buffer_copy(bytes(uid.cpu().numpy().tobytes()))
             comm = C.c_void_p()
             _lib.check(L.ppo_xp_rccl_comm_init(C.byref(comm), raw, rank, world))
             buf.set_exchange(1, comm.value)
         else:
-            buf.set_exchange(2)
+            sb = sharded.ShardedBatcher(buf, B * world)      # global batch = world x local batch; sets exchange mode 2
 
     def step(i):
         _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
         _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perms[i & 1].data_ptr())))
         if world > 1 and args.exchange == "torch":
-            dist.all_reduce(buf.pass_sums(K))
-            buf.pass_finish()
+            sb.exchange()                                    # ONE all-reduce of 3K doubles, then standardise
         bv = _lib.BatchView()
         n = 0
         while L.ppo_xp_pass_next(h, C.byref(bv)) == 0:
@@ -172,6 +178,7 @@ def main():
         assert n == K
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -197,7 +204,7 @@ def main():
     buf.prof_enable(False)
 
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -215,7 +222,7 @@ def main():
             "config": {"workload": f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
                                    "gamma=0.99 lambda=0.95, sequential GAE scan + one shuffled pass",
                        "global_envs": world * N, "parallelism": f"env-sharded x{world}" if world > 1 else "single GPU",
-                       "exchange": (args.exchange if world > 1 else "none")},
+                       "exchange": ((args.exchange + "/" + args.backend) if world > 1 else "none")},
             "hbm_roofline_frac_whole_step": value * alg_bytes_total(D) / (world * HBM_PEAK_GBS * 1e9),
             "alg_bytes_per_transition": alg_bytes_total(D),
             "roofline": {"bound": "hbm", "kernel": "obs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
