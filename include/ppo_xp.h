@@ -187,6 +187,22 @@ int ppo_xp_rccl_unique_id(void *out128);
 int ppo_xp_rccl_comm_init(void **comm_out, const void *unique_id128, int rank, int world);
 int ppo_xp_rccl_comm_destroy(void *comm);
 
+/* ---- reward normalisation, the step before add_experience (next row) ---- */
+
+/* VecRunner's reward side (ppo/src/common/runner.rs:43-66: gamma 0.99, epsilon 1e-8, cliprew 10)
+ * with its RunningMeanStd<Ix0> (ppo/src/common/running_mean_std.rs:16-34: mean 0, var 1, count 1e-4),
+ * resident on the device. */
+typedef struct ppo_xp_rnorm ppo_xp_rnorm;
+int ppo_xp_rnorm_create(ppo_xp_rnorm **out, int device, size_t num_envs, float gamma, float epsilon, float cliprew);
+void ppo_xp_rnorm_destroy(ppo_xp_rnorm *r);
+/* VecRunner::normalized_rewards (runner.rs:114-127) on host slices (dones: Rust bools). */
+int ppo_xp_rnorm_step(ppo_xp_rnorm *r, const float *rewards, const uint8_t *dones, float *out, size_t n);
+/* The same on device arrays (dones already 0.0/1.0); enqueued on `stream` (NULL = the object's own). */
+int ppo_xp_rnorm_step_device(ppo_xp_rnorm *r, const float *rewards_dev, const float *dones_f32_dev, float *out_dev,
+                             size_t n, void *stream);
+/* Running statistics (ret_rms.mean / .var / count) and, if ret_out != NULL, the n discounted returns. */
+int ppo_xp_rnorm_state(ppo_xp_rnorm *r, float *mean, float *var, float *count, float *ret_out, size_t n);
+
 /* ---- plumbing --------------------------------------------------------------------------- */
 
 void *ppo_xp_stream(const ppo_xp *h);            /* hipStream_t of the handle                */

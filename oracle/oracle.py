@@ -79,6 +79,12 @@ def lib() -> C.CDLL:
         L.orc_explained_variance.argtypes = [vp, vp, sz]
         L.orc_explained_variance_f64.restype = C.c_double
         L.orc_explained_variance_f64.argtypes = [vp, vp, sz]
+        L.orc_rnorm_new.restype = vp
+        L.orc_rnorm_new.argtypes = [sz, f32, f32, f32]
+        L.orc_rnorm_free.argtypes = [vp]
+        L.orc_rnorm_step.restype = i32
+        L.orc_rnorm_step.argtypes = [vp, vp, vp, vp, sz]
+        L.orc_rnorm_state.argtypes = [vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), vp]
         L.orc_max_threads.restype = i32
         _lib = L
     return _lib
@@ -322,6 +328,33 @@ def run_pass(streams, T, N, D, last_values_idx, last_dones, gamma, lam, perm, B,
                            _p(outs["values"]), _p(outs["neglogps"]), _p(outs["ret"]), _p(outs["advn"]), nthreads)
     outs["K"] = k
     return outs
+
+
+class OracleRewardNormalizer:
+    """VecRunner::normalized_rewards + RunningMeanStd<Ix0> (runner.rs:114-127, running_mean_std.rs:16-67)."""
+
+    def __init__(self, num_envs, gamma=0.99, epsilon=1e-8, cliprew=10.0):
+        self.N = int(num_envs)
+        self._h = lib().orc_rnorm_new(self.N, gamma, epsilon, cliprew)
+
+    def __del__(self):
+        try:
+            lib().orc_rnorm_free(self._h)
+        except Exception:
+            pass
+
+    def normalized_rewards(self, rewards, dones):
+        rewards, dones = _c(rewards, np.float32), _c(dones, np.uint8)
+        out = np.empty(self.N, np.float32)
+        if lib().orc_rnorm_step(self._h, _p(rewards), _p(dones), _p(out), rewards.size) != 0:
+            raise AssertionError("normalized_rewards: length mismatch")
+        return out
+
+    def state(self):
+        m, v, c = C.c_float(), C.c_float(), C.c_float()
+        ret = np.empty(self.N, np.float32)
+        lib().orc_rnorm_state(self._h, C.byref(m), C.byref(v), C.byref(c), _p(ret))
+        return m.value, v.value, c.value, ret
 
 
 def max_threads():

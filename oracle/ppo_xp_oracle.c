@@ -492,3 +492,66 @@ double orc_explained_variance_f64(const float *values, const float *returns, siz
   }
   return (double)(0.0L - (qd / n) / (qr / n));
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Reward normalisation (next row): ppo/src/common/runner.rs:114-127 +                      */
+/* ppo/src/common/running_mean_std.rs:16-67 (RunningMeanStd<Ix0>)                           */
+/* ------------------------------------------------------------------------------------ */
+typedef struct orc_rnorm {
+  size_t N;
+  float gamma, epsilon, cliprew;
+  float *ret;                 /* runner.rs:63 zeros */
+  float mean, var, count;     /* running_mean_std.rs:29-33: 0, 1, epsilon = 1e-4 */
+} orc_rnorm;
+
+orc_rnorm *orc_rnorm_new(size_t N, float gamma, float epsilon, float cliprew) {
+  orc_rnorm *r = (orc_rnorm *)calloc(1, sizeof(*r));
+  r->N = N; r->gamma = gamma; r->epsilon = epsilon; r->cliprew = cliprew;
+  r->ret = (float *)calloc(N ? N : 1, sizeof(float));
+  r->mean = 0.0f; r->var = 1.0f; r->count = 1e-4f;
+  return r;
+}
+void orc_rnorm_free(orc_rnorm *r) { if (r) { free(r->ret); free(r); } }
+
+/* ndarray 0.15.6 numeric_util::unrolled_fold as used by `sum()` of a contiguous lane (restated from
+ * the published crate source; ndarray is not on disk: PARITY UNPINNED). */
+static float orc_ndarray_sum(const float *x, size_t n) {
+  float acc = 0.0f, p[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) for (int k = 0; k < 8; ++k) p[k] = p[k] + x[i + k];
+  acc = acc + (p[0] + p[4]); acc = acc + (p[1] + p[5]); acc = acc + (p[2] + p[6]); acc = acc + (p[3] + p[7]);
+  for (; i < n; ++i) acc = acc + x[i];
+  return acc;
+}
+
+/* normalized_rewards — runner.rs:114-127.  Returns -1 on a length mismatch. */
+int orc_rnorm_step(orc_rnorm *r, const float *rews, const uint8_t *dones, float *out, size_t n) {
+  if (n != r->N) return -1;
+  const size_t N = r->N;
+  for (size_t e = 0; e < N; ++e) r->ret[e] = r->ret[e] * r->gamma + rews[e];      /* runner.rs:119 */
+  /* ret_rms.update(&ret) — running_mean_std.rs:35-43 */
+  const float batch_mean = orc_ndarray_sum(r->ret, N) / (float)N;                 /* mean_axis */
+  const float batch_var = orc_var_welford_f32(r->ret, N, 0.0f);                   /* var_axis(_, 0.) */
+  const float b_count = (float)N;
+  /* update_from_moments — running_mean_std.rs:45-67 */
+  const float delta = batch_mean - r->mean;
+  const float tot_count = r->count + b_count;
+  const float new_mean = r->mean + delta * b_count / tot_count;
+  const float m_a = r->var * r->count;
+  const float m_b = batch_var * b_count;
+  const float m2 = m_a + m_b + (delta * delta) * r->count * b_count / tot_count;
+  const float new_var = m2 / tot_count;
+  r->mean = new_mean; r->var = new_var; r->count = tot_count;
+  const float denom = sqrtf(r->var + r->epsilon);                                 /* runner.rs:121 */
+  for (size_t e = 0; e < N; ++e) {
+    float x = rews[e] / denom;
+    x = x < -r->cliprew ? -r->cliprew : (x > r->cliprew ? r->cliprew : x);        /* runner.rs:122 */
+    out[e] = x;
+    r->ret[e] = r->ret[e] * (float)(uint8_t)(dones[e] != 0);                      /* runner.rs:124 (sic) */
+  }
+  return 0;
+}
+void orc_rnorm_state(const orc_rnorm *r, float *mean, float *var, float *count, float *ret) {
+  *mean = r->mean; *var = r->var; *count = r->count;
+  if (ret) memcpy(ret, r->ret, r->N * sizeof(float));
+}

@@ -7,6 +7,7 @@ classes here mirror ppo/src/common/buffer.rs and ppo/src/model/data.rs.  There i
 from ._lib import GAE_ASSOC, GAE_NO_PACK, GAE_SEQUENTIAL, PpoXpError, PpoXpPanic, gae_chunk
 from .buffer import ExperienceBuffer, device_tensor
 from .data import ExperienceBatch, ExperienceBatcher, ExperienceBatcherIterator
+from .runner import RewardNormalizer
 
-__all__ = ["ExperienceBuffer", "ExperienceBatch", "ExperienceBatcher", "ExperienceBatcherIterator", "PpoXpError",
+__all__ = ["ExperienceBuffer", "ExperienceBatch", "ExperienceBatcher", "ExperienceBatcherIterator", "RewardNormalizer", "PpoXpError",
            "PpoXpPanic", "GAE_SEQUENTIAL", "GAE_ASSOC", "GAE_NO_PACK", "gae_chunk", "device_tensor"]

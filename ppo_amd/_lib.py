@@ -78,6 +78,11 @@ SYMBOLS = {
     "ppo_xp_rccl_unique_id": (_i, [_vp]),
     "ppo_xp_rccl_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
     "ppo_xp_rccl_comm_destroy": (_i, [_vp]),
+    "ppo_xp_rnorm_create": (_i, [C.POINTER(_vp), _i, _sz, _f, _f, _f]),
+    "ppo_xp_rnorm_destroy": (None, [_vp]),
+    "ppo_xp_rnorm_step": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "ppo_xp_rnorm_step_device": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "ppo_xp_rnorm_state": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _vp, _sz]),
     "ppo_xp_stream": (_vp, [_vp]),
     "ppo_xp_set_stream": (_i, [_vp, _vp]),
     "ppo_xp_sync": (_i, [_vp]),

@@ -20,6 +20,7 @@
 #include "kernels_gather.h"
 #include "shuffle.h"
 #include "device_shuffle.h"
+#include "errors.h"
 
 using namespace ppoxp;
 
@@ -28,7 +29,7 @@ using namespace ppoxp;
 // ---------------------------------------------------------------------------------------
 static thread_local std::string g_err;
 
-static int fail(int code, const char *fmt, ...) {
+int ppoxp_fail(int code, const char *fmt, ...) {
   char buf[512];
   va_list ap;
   va_start(ap, fmt);
@@ -37,6 +38,7 @@ static int fail(int code, const char *fmt, ...) {
   g_err = buf;
   return code;
 }
+#define fail ppoxp_fail
 
 #define HIP_TRY(expr)                                                                          \
   do {                                                                                         \

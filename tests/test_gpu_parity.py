@@ -392,3 +392,41 @@ def test_explained_variance(xp, oracle, T, N):
     assert abs(ev - oracle.explained_variance_f64(val, ret)) < 2e-6 * max(1.0, abs(ev))
     assert abs(ev - oracle.explained_variance(val, ret)) < 2e-5 * max(1.0, abs(ev))
     g.close()
+
+
+@pytest.mark.parametrize("N", [1, 7, 300, 4096])
+def test_reward_normalizer(xp, oracle, N):
+    """runner.rs:114-127 + running_mean_std.rs over 40 steps, incl. the `ret *= dones` quirk.
+    ndarray's reduction order is unpinned and the kernel reduces in fp64: tolerances, not bits."""
+    g = xp.RewardNormalizer(N)
+    o = oracle.OracleRewardNormalizer(N)
+    rng = np.random.default_rng(N)
+    for step in range(40):
+        rews = (rng.standard_normal(N) * (1 + step % 5)).astype(np.float32)
+        if step == 7:
+            rews[0] = 1e4            # hits the clip
+        dones = rng.random(N) < 0.3
+        a, b = g.normalized_rewards(rews, dones), o.normalized_rewards(rews, dones)
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=1e-6)
+        assert np.abs(a).max() <= 10.0
+    gm, gv, gc, gret = g.state()
+    om, ov, oc, oret = o.state()
+    assert gc == oc
+    assert abs(gm - om) <= 2e-5 * max(1.0, abs(om)) and abs(gv - ov) <= 2e-5 * max(1.0, abs(ov))
+    np.testing.assert_array_equal(bits(gret), bits(oret))     # ret = (ret*gamma + r) * dones is elementwise: exact
+    with pytest.raises(AssertionError):
+        g.normalized_rewards(np.zeros(N + 1, np.float32), np.zeros(N + 1, bool))
+    g.close()
+
+
+def test_reward_normalizer_device_tensors(xp, oracle):
+    import torch
+    N = 1000
+    g, o = xp.RewardNormalizer(N), oracle.OracleRewardNormalizer(N)
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        rews = rng.standard_normal(N).astype(np.float32)
+        dones = rng.random(N) < 0.5
+        out = g.normalized_rewards(torch.from_numpy(rews).cuda(), torch.from_numpy(dones.astype(np.float32)).cuda())
+        np.testing.assert_allclose(out.cpu().numpy(), o.normalized_rewards(rews, dones), rtol=2e-5, atol=1e-6)
+    g.close()
