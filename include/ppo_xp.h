@@ -221,7 +221,7 @@ int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launc
 const char *ppo_xp_kernel_name(int kernel_id);
 
 /* Tunables (A/B measurements in one process): "gather_nt" 0/1, "gather_block" 64/256,
- * "gae_unroll" 4/8/16, "carry_waves" 4/8/16.  Unknown names or values => PPO_XP_EINVAL. */
+ * "gae_unroll" 0 (auto)/4/8/16, "carry_waves" 4/8/16.  Unknown names or values => PPO_XP_EINVAL. */
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
 
 const char *ppo_xp_last_error(void);

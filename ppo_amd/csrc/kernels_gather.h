@@ -187,16 +187,18 @@ __device__ __forceinline__ void stats_from_sums(const double *s, float &mean, fl
   stdv = sqrtf(corrected);
 }
 
-// In-place standardisation of adv_out[k*B .. (k+1)*B).  grid = (ceil(B / 1024), K), block = 256,
-// four consecutive floats per thread (16-byte accesses when the minibatch base allows it).
+// In-place standardisation of adv_out[k*B .. (k+1)*B).  grid = K * tiles_per_mb blocks (1-D, so K
+// is not limited by gridDim.y), tiles_per_mb = ceil(B / 1024), block = 256, four consecutive floats
+// per thread (16-byte accesses when the minibatch base allows it).
 __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_out, const double *__restrict__ sums,
-                                                        float *__restrict__ stats, size_t B) {
-  const unsigned k = blockIdx.y;
+                                                        float *__restrict__ stats, size_t B, unsigned tiles_per_mb) {
+  const unsigned k = blockIdx.x / tiles_per_mb;
+  const unsigned bx = blockIdx.x - k * tiles_per_mb;
   float mean, stdv;
-  stats_from_sums(sums + 3 * k, mean, stdv);
+  stats_from_sums(sums + 3 * (size_t)k, mean, stdv);
   const float denom = stdv + 1e-8f;
   float *a = adv_out + (size_t)k * B;
-  const size_t j = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+  const size_t j = ((size_t)bx * 256u + threadIdx.x) * 4u;
   if (j + 4 <= B && ((reinterpret_cast<uintptr_t>(a + j) & 15u) == 0)) {
     f32x4 x = *reinterpret_cast<f32x4 *>(a + j);
     x.x = (x.x - mean) / denom; x.y = (x.y - mean) / denom; x.z = (x.z - mean) / denom; x.w = (x.w - mean) / denom;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_
   } else {
     for (size_t i = j; i < B && i < j + 4; ++i) a[i] = (a[i] - mean) / denom;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) { stats[2 * k] = mean; stats[2 * k + 1] = stdv; }
+  if (bx == 0 && threadIdx.x == 0) { stats[2 * (size_t)k] = mean; stats[2 * (size_t)k + 1] = stdv; }
 }
 
 // explained_variance (ppo/src/training.rs:88-99) needs var(returns) and var(returns - values), both

@@ -189,6 +189,7 @@ def test_reference_batcher_sanity(xp):
     (1, 1, 1, 1),          # single transition: standardisation is NaN (n = 1)
     (6, 3, 2, 18),         # B == M: one batch
     (6, 3, 2, 19),         # B > M: empty pass (data.rs:117)
+    (1100, 64, 1, 1),      # K = 70 400 minibatches of one row (more than gridDim.y could hold)
 ])
 def test_seeded_parity(xp, oracle, T, N, D, B):
     g, o, r = both(xp, oracle, T, N, D, T, seed=T * 1000 + N, p_done=0.1)
