@@ -215,8 +215,12 @@ def main():
         g_avg_s = g_ms / max(g_n, 1) * 1e-3
         achieved = M * alg_bytes_obs_gather(D) / g_avg_s / 1e9 if g_n else 0.0
         kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            metric = "transitions/sec through GAE+norm+minibatch gather; % of HBM roofline, 1\u20138 GPU"
         out = {
-            "metric": "transitions/sec through GAE+norm+minibatch gather", "value": value, "unit": "transitions/s",
+            "metric": metric, "value": value, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "

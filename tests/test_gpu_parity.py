@@ -431,3 +431,63 @@ def test_reward_normalizer_device_tensors(xp, oracle):
         out = g.normalized_rewards(torch.from_numpy(rews).cuda(), torch.from_numpy(dones.astype(np.float32)).cuda())
         np.testing.assert_allclose(out.cpu().numpy(), o.normalized_rewards(rews, dones), rtol=2e-5, atol=1e-6)
     g.close()
+
+
+# ---- lifecycle: the call pattern of train() (training.rs:160-211) ------------------------------
+
+def test_train_loop_lifecycle(xp, oracle):
+    """reset_counter -> T x add_experience -> returns -> num_train_iterations passes with fresh
+    permutations, for several epochs on ONE handle, batch size changing between epochs (slabs are
+    re-allocated), with the previous step's dones inserted (training.rs:161,177,181)."""
+    from ppo_amd import synth
+    N, D, T = 12, 5, 9
+    g, o = xp.ExperienceBuffer.new(N, D, T), oracle.OracleBuffer(N, D, T)
+    for epoch, B in enumerate([27, 108, 10, 50]):
+        r = synth.rollout(T, N, D, 1000 + epoch, 0.2)
+        g.reset_counter(); o.reset_counter()
+        dones = np.zeros(N, bool)                                 # training.rs:161
+        for t in range(T):
+            step = (r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], dones, r["neglogps"][t])
+            g.add_experience(*step); o.add_experience(*step)      # training.rs:172-179
+            dones = r["dones"][t].astype(bool)                    # training.rs:181
+        for it in range(3):                                       # training.rs:204-205
+            check_pass(xp, oracle, g, o, dones, B, seed=77 * epoch + it)
+        ev = g.explained_variance()                               # training.rs:189
+        assert np.isfinite(ev)
+    g.close()
+
+
+def test_two_handles_interleaved(xp, oracle):
+    """Distinct handles are independent (one per GPU / rank in the sharded job): interleaving their
+    calls must not mix state, streams or scratch."""
+    from ppo_amd import synth
+    ra, rb = synth.rollout(8, 70, 4, 1, 0.1), synth.rollout(6, 33, 7, 2, 0.1)
+    ga, gb = xp.ExperienceBuffer(70, 4, 8), xp.ExperienceBuffer(33, 7, 6)
+    oa, ob = oracle.OracleBuffer(70, 4, 8), oracle.OracleBuffer(33, 7, 6)
+    for t in range(8):
+        ga.add_experience(ra["obs"][t], ra["rewards"][t], ra["actions"][t], ra["values"][t], ra["dones"][t], ra["neglogps"][t])
+        oa.add_experience(ra["obs"][t], ra["rewards"][t], ra["actions"][t], ra["values"][t], ra["dones"][t], ra["neglogps"][t])
+        if t < 6:
+            gb.add_experience(rb["obs"][t], rb["rewards"][t], rb["actions"][t], rb["values"][t], rb["dones"][t], rb["neglogps"][t])
+            ob.add_experience(rb["obs"][t], rb["rewards"][t], rb["actions"][t], rb["values"][t], rb["dones"][t], rb["neglogps"][t])
+    reta, retb = ga.returns(ra["last_dones"]), gb.returns(rb["last_dones"])
+    ita = xp.ExperienceBatcher(ga, 100).into_iter(seed=3)
+    itb = xp.ExperienceBatcher(gb, 40).into_iter(seed=4)
+    ba, bb = list(ita), list(itb)
+    pa, pb = ita.perm(), itb.perm()
+    np.testing.assert_array_equal(bits(reta.cpu().numpy()), bits(oa.returns(ra["last_dones"])))
+    np.testing.assert_array_equal(bits(retb.cpu().numpy()), bits(ob.returns(rb["last_dones"])))
+    obs_a, obs_b = ra["obs"].reshape(-1, 4), rb["obs"].reshape(-1, 7)
+    for (s, e), b in zip(oracle.batch_windows(560, 100), ba):
+        np.testing.assert_array_equal(b.observations.cpu().numpy(), obs_a[pa[s:e]])
+    for (s, e), b in zip(oracle.batch_windows(198, 40), bb):
+        np.testing.assert_array_equal(b.observations.cpu().numpy(), obs_b[pb[s:e]])
+    ga.close(); gb.close()
+
+
+@pytest.mark.parametrize("T,N,D,B", [(1, 1, 1023, 1), (2, 3, 1000, 5), (3, 257, 12, 771), (1, 4099, 1, 1000), (7, 1, 8, 3)])
+def test_odd_shapes(xp, oracle, T, N, D, B):
+    """capacity 1, one env, wide / odd observation rows, N just above a multiple of 64 and 4096."""
+    g, o, r = both(xp, oracle, T, N, D, T, seed=T + N + D, p_done=0.3)
+    check_pass(xp, oracle, g, o, r["last_dones"], B, seed=1)
+    g.close()
