@@ -67,11 +67,15 @@ __device__ __forceinline__ void gae_step(float r, float v, float v_next, float n
 // K1 (and the fix-up phase of K2): sequential reverse-time scan, one lane per env.
 // grid = (ceil(N/64), C), block = 64.  blockIdx.y = time chunk (C = 1 for the pure sequential
 // algorithm).  Loads of the next U time steps are issued before the current U are consumed.
-template <bool PACK, int U>
+// SUMMARY = true turns the same loop into phase 1 of K2: chunk index = blockIdx.y + 1 (chunk 0 feeds
+// nobody), carry-in 0, nothing stored per step, and at the end the chunk's affine map
+//   A_{t_lo} = Q + P * A_{t_hi+1},   P = prod fl(nnt_{t+1} * gl),  Q = the scan started from 0
+// goes to sumP / sumQ.  Q is computed with exactly the sequential kernel's operations.
+template <bool PACK, int U, bool SUMMARY = false>
 __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
   const unsigned e = blockIdx.x * 64u + threadIdx.x;
   if (e >= a.N) return;
-  const unsigned c = blockIdx.y;
+  const unsigned c = SUMMARY ? blockIdx.y + 1 : blockIdx.y;
   const int t_lo = (int)(c * a.chunk);
   int t_hi = (int)min((c + 1) * a.chunk, a.len) - 1;
   if (t_hi < t_lo) return;
@@ -85,8 +89,9 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
   } else {                                     // buffer.rs:212-213, 199
     v_next = a.values[(size_t)(t_hi + 1) * N + e];
     nnt_next = 1.0f - a.dones[(size_t)(t_hi + 1) * N + e];
-    A = a.carry[(size_t)c * N + e];
+    A = SUMMARY ? 0.0f : a.carry[(size_t)c * N + e];
   }
+  float P = 1.0f;
 
   float r[U], v[U], d[U], nl[U];
   int64_t ac[U];
@@ -121,62 +126,23 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
       int t = t_top - u;
       if (t >= t_lo) {
         float ret, adv;
+        if (SUMMARY) P = P * (nnt_next * a.gl);
         gae_step(rc[u], vc[u], v_next, nnt_next, a.gamma, a.gl, A, ret, adv);
-        size_t i = (size_t)t * N + e;
-        if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
-        else { a.returns[i] = ret; a.adv[i] = adv; }
-        if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
+        if (!SUMMARY) {
+          size_t i = (size_t)t * N + e;
+          if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
+          else { a.returns[i] = ret; a.adv[i] = adv; }
+          if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
+        }
         v_next = vc[u];
         nnt_next = 1.0f - dc[u];
       }
     }
   }
-}
-
-// K2 phase 1: per (chunk c >= 1, env) summary of the chunk's affine map  A_in -> A_out:
-//   A_{t} = delta_t + a_t * A_{t+1},  a_t = fl(nnt_{t+1} * gl)
-// composed over the chunk:  A_{t_lo} = Q + P * A_{t_hi+1}.  Q is computed with exactly the
-// sequential kernel's operations (carry-in 0); P is the running product of the a_t.
-// grid = (ceil(N/64), C-1): chunk index = blockIdx.y + 1 (chunk 0 feeds nobody).
-template <int U>
-__global__ __launch_bounds__(64) void gae_chunk_summary_kernel(GaeArgs a) {
-  const unsigned e = blockIdx.x * 64u + threadIdx.x;
-  if (e >= a.N) return;
-  const unsigned c = blockIdx.y + 1;
-  const int t_lo = (int)(c * a.chunk);
-  int t_hi = (int)min((c + 1) * a.chunk, a.len) - 1;
-  if (t_hi < t_lo) return;
-  const size_t N = a.N;
-  float v_next, nnt_next;
-  if ((unsigned)t_hi == a.len - 1) {
-    v_next = a.values[(size_t)a.lvi * N + e];
-    nnt_next = a.last_dones[e] ? 0.0f : 1.0f;
-  } else {
-    v_next = a.values[(size_t)(t_hi + 1) * N + e];
-    nnt_next = 1.0f - a.dones[(size_t)(t_hi + 1) * N + e];
+  if (SUMMARY) {
+    a.sumP[(size_t)c * N + e] = P;
+    a.sumQ[(size_t)c * N + e] = A;
   }
-  float P = 1.0f, Q = 0.0f;
-  for (int t_top = t_hi; t_top >= t_lo; t_top -= U) {
-    float r[U], v[U], d[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int t = max(t_top - u, t_lo);
-      size_t i = (size_t)t * N + e;
-      r[u] = a.rewards[i]; v[u] = a.values[i]; d[u] = a.dones[i];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t_top - u >= t_lo) {
-        float ret, adv;
-        P = P * (nnt_next * a.gl);
-        gae_step(r[u], v[u], v_next, nnt_next, a.gamma, a.gl, Q, ret, adv);
-        v_next = v[u];
-        nnt_next = 1.0f - d[u];
-      }
-    }
-  }
-  a.sumP[(size_t)c * N + e] = P;
-  a.sumQ[(size_t)c * N + e] = Q;
 }
 
 // K2 phase 2: LDS-staged associative scan over the chunk summaries.

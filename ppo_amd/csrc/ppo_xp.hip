@@ -129,7 +129,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0;
 };
 
 namespace {
@@ -237,8 +237,10 @@ int run_gae(ppo_xp *h, int algo) {
     {
       dim3 grid((unsigned)((N + 63) / 64), chunks - 1), block(64);
       ProfScope ps(h, PPO_XP_K_GAE_SUMMARY);
-      hipLaunchKernelGGL((gae_chunk_summary_kernel<8>), grid, block, 0, h->stream, a);
-      if (int rc = launch_check("gae_chunk_summary_kernel")) return rc;
+      GaeArgs sa = a;
+      sa.nt = (int)h->summary_nt;   // default policy: the fix-up pass reads the same bytes again
+      hipLaunchKernelGGL((gae_scan_kernel<false, 8, true>), grid, block, 0, h->stream, sa);
+      if (int rc = launch_check("gae_scan_kernel<summary>")) return rc;
     }
     {
       dim3 grid((unsigned)((N + 63) / 64));
@@ -797,6 +799,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
   else if (n == "gather_block" && (value == 64 || value == 256)) h->gather_block = value;
   else if (n == "gather_xcd" && value >= 0 && value <= 2) h->gather_xcd = value;
+  else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
