@@ -90,6 +90,12 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
+    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line
+    # there.  Everything below writes to stderr's file until the result is printed.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -102,8 +108,14 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # PPO_XP_FORCE_PG=1: run the multi-rank control flow (process group, exchange, barriers) with ONE
+    # rank, the only RCCL rehearsal a one-GPU box allows
+    multi = world > 1 or os.environ.get("PPO_XP_FORCE_PG") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -150,7 +162,7 @@ def main():
 
     # ---- exchange of the per-minibatch sums across ranks (the only cross-GPU step) -----------
     comm = None
-    if world > 1:
+    if multi:
         if args.exchange == "rccl":
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -169,7 +181,7 @@ def main():
     def step(i):
         _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
         _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perms[i & 1].data_ptr())))
-        if world > 1 and args.exchange == "torch":
+        if multi and args.exchange == "torch":
             sb.exchange()                                    # ONE all-reduce of 3K doubles, then standardise
         bv = _lib.BatchView()
         n = 0
@@ -179,7 +191,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -203,7 +215,7 @@ def main():
     prof_all = buf.prof_collect()
     buf.prof_enable(False)
 
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -225,8 +237,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
                                    "gamma=0.99 lambda=0.95, sequential GAE scan + one shuffled pass",
-                       "global_envs": world * N, "parallelism": f"env-sharded x{world}" if world > 1 else "single GPU",
-                       "exchange": ((args.exchange + "/" + args.backend) if world > 1 else "none")},
+                       "global_envs": world * N, "parallelism": f"env-sharded x{world}" if multi else "single GPU",
+                       "exchange": ((args.exchange + "/" + args.backend) if multi else "none")},
             "hbm_roofline_frac_whole_step": value * alg_bytes_total(D) / (world * HBM_PEAK_GBS * 1e9),
             "alg_bytes_per_transition": alg_bytes_total(D),
             "roofline": {"bound": "hbm", "kernel": "obs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -247,13 +259,14 @@ def main():
                 pass
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(T, D, K)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     if comm is not None:
         buf.sync()
         L.ppo_xp_rccl_comm_destroy(comm)
     buf.close()
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

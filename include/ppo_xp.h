@@ -220,8 +220,11 @@ int ppo_xp_prof_enable(ppo_xp *h, int enable);
 int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launches_out /*[K_COUNT]*/);
 const char *ppo_xp_kernel_name(int kernel_id);
 
-/* Tunables (A/B measurements in one process): "gather_nt" 0/1, "gather_block" 64/256,
- * "gae_unroll" 0 (auto)/4/8/16, "carry_waves" 4/8/16.  Unknown names or values => PPO_XP_EINVAL. */
+/* Tunables (A/B measurements in one process; results never depend on them except through the
+ * documented tolerance of PPO_XP_GAE_ASSOC): "gather_nt" 0/1, "gather_block" 64/256, "gather_xcd" 0/1/2,
+ * "gae_waves" 0 (auto)/1/2/4/8/16 (waves per 64 envs of the sequential scan), "gae_unroll" 0 (auto)/4/8/16,
+ * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams).
+ * Unknown names or values => PPO_XP_EINVAL. */
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
 
 const char *ppo_xp_last_error(void);

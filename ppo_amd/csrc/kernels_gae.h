@@ -145,6 +145,109 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
   }
 }
 
+// K1w: the same sequential scan with W waves per 64 envs, for launches with too few env groups to
+// cover the memory latency with one wave each (C2: 64 groups, C3: 256).  The scan is cut into
+// super-chunks of W*S time steps; wave w of the workgroup owns S consecutive steps of the
+// super-chunk and loads them (and the next super-chunk's) into registers, so W*S steps per env are
+// in flight instead of U.  Everything that does not depend on the running A (delta and the
+// non-terminal factors) is computed by all waves at once; only the three dependent operations per
+// step  y1 = nnt*A, y2 = y1*gl, A = delta + y2  run wave after wave, the carry handed over through
+// LDS.  Operations and their order per (t, e) are exactly gae_step's: results are bit-identical to
+// gae_scan_kernel.  grid = ceil(N/64), block = 64*W.  Lanes past N work on a clamped env and store
+// nothing, so every wave reaches every barrier.
+template <bool PACK, int W, int S>
+__global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
+  __shared__ float carry[64];
+  const unsigned lane = threadIdx.x & 63u;
+  const int w = (int)(threadIdx.x >> 6);
+  const unsigned e_raw = blockIdx.x * 64u + lane;
+  const bool live = e_raw < a.N;
+  const size_t N = a.N;
+  const size_t e = live ? e_raw : N - 1;
+  const int len = (int)a.len;
+  constexpr int span = W * S;
+
+  float r[S], v[S], d[S], nl[S], vb, db;      // vb, db: value / done flag of the row above the slice
+  int64_t ac[S];
+  auto load = [&](int top) {                  // top = latest time step of this wave's slice (may be < 0: empty)
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      const size_t i = (size_t)max(top - u, 0) * N + e;
+      if (a.nt) {
+        r[u] = __builtin_nontemporal_load(a.rewards + i);
+        v[u] = __builtin_nontemporal_load(a.values + i);
+        d[u] = __builtin_nontemporal_load(a.dones + i);
+        if (PACK) { nl[u] = __builtin_nontemporal_load(a.neglogps + i); ac[u] = __builtin_nontemporal_load(a.actions + i); }
+      } else {
+        r[u] = a.rewards[i]; v[u] = a.values[i]; d[u] = a.dones[i];
+        if (PACK) { nl[u] = a.neglogps[i]; ac[u] = a.actions[i]; }
+      }
+    }
+    if (top >= len - 1) {                     // buffer.rs:209-210, 201-204 (1 - 1 = 0, 1 - 0 = 1: same factors)
+      vb = a.values[(size_t)a.lvi * N + e];
+      db = a.last_dones[e] ? 1.0f : 0.0f;
+    } else {                                  // buffer.rs:212-213, 199
+      const size_t i = (size_t)max(top + 1, 0) * N + e;
+      vb = a.values[i];
+      db = a.dones[i];
+    }
+  };
+
+  load(len - 1 - w * S);
+  for (int sc_top = len - 1; sc_top >= 0; sc_top -= span) {
+    const int top = sc_top - w * S;
+    float rc[S], vc[S], dc[S], nlc[S];
+    int64_t acc[S];
+#pragma unroll
+    for (int u = 0; u < S; ++u) { rc[u] = r[u]; vc[u] = v[u]; dc[u] = d[u]; if (PACK) { nlc[u] = nl[u]; acc[u] = ac[u]; } }
+    float v_next = vb, nnt_next = 1.0f - db;
+    if (sc_top - span >= 0) load(sc_top - span - w * S);   // next super-chunk (workgroup-uniform)
+
+    float delta[S], nnt[S];                   // the part of gae_step that does not depend on A
+#pragma unroll
+    for (int u = 0; u < S; ++u) {
+      float x1 = v_next * nnt_next;
+      float x2 = x1 * a.gamma;
+      float x3 = rc[u] + x2;
+      delta[u] = x3 - vc[u];
+      nnt[u] = nnt_next;
+      v_next = vc[u];
+      nnt_next = 1.0f - dc[u];
+    }
+#pragma unroll 1
+    for (int p = 0; p < W; ++p) {
+      if (w == p) {                           // wave-uniform
+        float A = (p == 0 && sc_top == len - 1) ? 0.0f : carry[lane];   // buffer.rs:196
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+          if (top - u >= 0) {
+            float y1 = nnt[u] * A;
+            float y2 = y1 * a.gl;
+            A = delta[u] + y2;
+            delta[u] = A;                     // keep A_t for the stores below
+          }
+        }
+        carry[lane] = A;
+      }
+      if (W > 1) __syncthreads();
+      if (w == p && live) {                   // stores overlap the next wave's dependent chain
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+          const int t = top - u;
+          if (t >= 0) {
+            const float ret = delta[u] + vc[u];          // buffer.rs:222
+            const float adv = ret - vc[u];               // data.rs:62
+            const size_t i = (size_t)t * N + e;
+            if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
+            else { a.returns[i] = ret; a.adv[i] = adv; }
+            if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // K2 phase 2: LDS-staged associative scan over the chunk summaries.
 // carry[c] = A entering chunk c from the future:  carry[C-1] = 0,
 //            carry[c] = Q[c+1] + P[c+1] * carry[c+1].

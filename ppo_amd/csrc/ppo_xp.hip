@@ -129,7 +129,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0;
 };
 
 namespace {
@@ -195,6 +195,34 @@ int launch_gae_scan(ppo_xp *h, const GaeArgs &a, unsigned chunks) {
   return launch_check("gae_scan_kernel");
 }
 
+// K1w: W waves per env group, S = 8 steps per wave and super-chunk.  W = 0: one wave (gae_scan_kernel).
+unsigned pick_gae_waves(const ppo_xp *h, size_t len) {
+  if (h->gae_waves > 0) return (unsigned)h->gae_waves == 1 ? 0u : (unsigned)h->gae_waves;
+  // measured (profiles/r1/tune_gae_waves.log): C2 (64 env groups) 23.2 us with one wave per group,
+  // 16.9 / 13.5 / 12.5 / 13.8 us with 2 / 4 / 8 / 16; TGT (1024 groups) 70.5 us with one wave, slower with more
+  const size_t groups = (h->N + 63) / 64;
+  unsigned w = 1;
+  while (w < 8 && groups * w < 512) w <<= 1;
+  while (w > 1 && (size_t)(w / 2) * 8 >= len) w >>= 1;   // no more waves than slices of 8 steps
+  return w > 1 ? w : 0;
+}
+
+template <bool PACK>
+int launch_gae_wide(ppo_xp *h, const GaeArgs &a, unsigned W) {
+  dim3 grid((unsigned)((h->N + 63) / 64));
+  ProfScope ps(h, PPO_XP_K_GAE);
+  switch (W) {
+    case 2: hipLaunchKernelGGL((gae_wide_kernel<PACK, 2, 8>), grid, dim3(128), 0, h->stream, a); break;
+    case 4: hipLaunchKernelGGL((gae_wide_kernel<PACK, 4, 8>), grid, dim3(256), 0, h->stream, a); break;
+    case 8: hipLaunchKernelGGL((gae_wide_kernel<PACK, 8, 8>), grid, dim3(512), 0, h->stream, a); break;
+    default:   // 1024-thread workgroups have 128 VGPRs per lane: the packing variant holds 4 steps per wave there
+      if (PACK) hipLaunchKernelGGL((gae_wide_kernel<PACK, 16, 4>), grid, dim3(1024), 0, h->stream, a);
+      else hipLaunchKernelGGL((gae_wide_kernel<PACK, 16, 8>), grid, dim3(1024), 0, h->stream, a);
+      break;
+  }
+  return launch_check("gae_wide_kernel");
+}
+
 int run_gae(ppo_xp *h, int algo) {
   const size_t len = buf_len(h);
   const size_t N = h->N;
@@ -254,7 +282,10 @@ int run_gae(ppo_xp *h, int algo) {
       if (int rc = launch_check("gae_carry_scan_kernel")) return rc;
     }
   }
-  int rc = pack ? launch_gae_scan<true>(h, a, chunks) : launch_gae_scan<false>(h, a, chunks);
+  const unsigned W = chunks == 1 ? pick_gae_waves(h, len) : 0u;
+  int rc;
+  if (W) rc = pack ? launch_gae_wide<true>(h, a, W) : launch_gae_wide<false>(h, a, W);
+  else rc = pack ? launch_gae_scan<true>(h, a, chunks) : launch_gae_scan<false>(h, a, chunks);
   if (rc) return rc;
   h->have_returns = true;
   h->have_rec = pack;
@@ -799,6 +830,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
   else if (n == "gather_block" && (value == 64 || value == 256)) h->gather_block = value;
   else if (n == "gather_xcd" && value >= 0 && value <= 2) h->gather_xcd = value;
+  else if (n == "gae_waves" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) h->gae_waves = value;
   else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;

@@ -310,6 +310,23 @@ def test_golden_fixtures(xp, name):
     g.close()
 
 
+# ---- multi-wave sequential scan (K1w) ---------------------------------------------------------------
+
+@pytest.mark.parametrize("waves", [1, 2, 4, 8, 16])
+@pytest.mark.parametrize("T,N,cap,steps", [(128, 70, 128, 128), (1, 3, 1, 1), (9, 64, 9, 9), (300, 130, 300, 300),
+                                           (0, 10, 40, 93), (0, 65, 200, 77)])
+def test_wide_scan_is_bit_identical(xp, oracle, waves, T, N, cap, steps):
+    """gae_wide_kernel<W> (W waves per 64 envs, slices of 8 steps) performs gae_step's operations in
+    gae_step's order: returns, advantages and the packed records are bit-identical to the oracle for
+    every W, for lengths that are not multiples of the super-chunk, partial buffers and wrapped rings."""
+    import ppo_amd
+    for algo in (0, ppo_amd.GAE_NO_PACK):
+        g, o, r = both(xp, oracle, T, N, 2, cap, seed=300 + steps + N, p_done=0.07, steps=steps, bulk=True)
+        g.set_tunable("gae_waves", waves)
+        check_pass(xp, oracle, g, o, r["last_dones"], 97, seed=waves, algo=algo)
+        g.close()
+
+
 # ---- associative scan (K2) ----------------------------------------------------------------------
 
 @pytest.mark.parametrize("T,N,chunk", [(128, 8, 0), (1000, 70, 0), (1000, 70, 7), (4096, 64, 64), (513, 3, 512), (64, 130, 1)])
