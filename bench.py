@@ -81,7 +81,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="TGT", help="TGT | C2 | C3 (per-GPU shard of the workload)")
+    ap.add_argument("--config", default="TGT",
+                    help="TGT | C2 | C3: every rank owns the config's N envs; C5: its 1 048 576 envs and batch are split "
+                         "over the ranks; C4: GAE only (T=16384, N=1024)")
+    ap.add_argument("--gae", default=None, choices=["seq", "assoc"], help="GAE algorithm (default: seq; assoc for C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
     ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
@@ -125,8 +128,15 @@ def main():
     from ppo_amd import _lib, sharded, synth
 
     T, N, D, B = synth.CONFIGS[args.config]   # per-GPU shard: weak scaling, every rank owns N envs
+    if args.config == "C5":                   # N/G envs and B/G rows per GPU
+        assert N % world == 0 and B % world == 0
+        N, B = N // world, B // world
+    gae_only = B == 0
     M = T * N
-    K = M // B
+    K = 0 if gae_only else M // B
+    algo = {"seq": 0, "assoc": 1}[args.gae or ("assoc" if args.config == "C4" else "seq")]
+    if gae_only:
+        algo |= 0x100                         # PPO_XP_GAE_NO_PACK: no pass follows, no records needed
     seed = synth.SEEDS[args.config] + 1000 * rank
 
     buf = ppo_amd.ExperienceBuffer(N, D, T, device=local_rank)
@@ -151,18 +161,19 @@ def main():
     # ---- permutations (host Fisher-Yates in the library, seeded; not timed) ------------------
     t0 = time.perf_counter()
     ld_p = last_dones.ctypes.data_as(C.c_void_p)
-    _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
+    _lib.check(L.ppo_xp_returns(h, ld_p, N, algo, None))
     perms = []
-    for i in range(2):
+    for i in range(0 if gae_only else 2):
         _lib.check(L.ppo_xp_pass_begin(h, B, None, seed + i))
         p = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, local_rank, buf)
         buf.sync()
         perms.append(p.clone())
     t_perm = (time.perf_counter() - t0) / 2
+    exch = multi and not gae_only     # the exchange of minibatch sums only exists when there is a pass
 
     # ---- exchange of the per-minibatch sums across ranks (the only cross-GPU step) -----------
     comm = None
-    if multi:
+    if exch:
         if args.exchange == "rccl":
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -179,9 +190,11 @@ def main():
             sb = sharded.ShardedBatcher(buf, B * world)      # global batch = world x local batch; sets exchange mode 2
 
     def step(i):
-        _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
+        _lib.check(L.ppo_xp_returns(h, ld_p, N, algo, None))
+        if gae_only:
+            return
         _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perms[i & 1].data_ptr())))
-        if multi and args.exchange == "torch":
+        if exch and args.exchange == "torch":
             sb.exchange()                                    # ONE all-reduce of 3K doubles, then standardise
         bv = _lib.BatchView()
         n = 0
@@ -199,7 +212,8 @@ def main():
         step(i)
     barrier()
     # timed region: HIP events only around the dominant kernel (an event pair costs ~7 us of stream time)
-    buf.prof_enable(False if args.no_kernel_events else ["gather"])
+    dom = "gae_scan" if gae_only else "gather"      # the dominant kernel of the step
+    buf.prof_enable(False if args.no_kernel_events else [dom])
     buf.prof_collect()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -223,9 +237,11 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         value = world * M * args.steps / dt
-        g_ms, g_n = prof["gather"]
+        g_ms, g_n = prof[dom]
         g_avg_s = g_ms / max(g_n, 1) * 1e-3
-        achieved = M * alg_bytes_obs_gather(D) / g_avg_s / 1e9 if g_n else 0.0
+        dom_bytes = 20 if gae_only else alg_bytes_obs_gather(D)     # per transition, SURVEY.md 8(d)
+        step_bytes = 20 if gae_only else alg_bytes_total(D)
+        achieved = M * dom_bytes / g_avg_s / 1e9 if g_n else 0.0
         kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
@@ -235,15 +251,17 @@ def main():
             "metric": metric, "value": value, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
-                                   "gamma=0.99 lambda=0.95, sequential GAE scan + one shuffled pass",
+            "config": {"workload": (f"{args.config}: T={T}, N={N} envs per GPU, GAE + returns only, "
+                                    f"{'associative (chunked)' if algo & 1 else 'sequential'} scan, gamma=0.99 lambda=0.95") if gae_only else
+                                   (f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
+                                    f"gamma=0.99 lambda=0.95, {'associative' if algo & 1 else 'sequential'} GAE scan + one shuffled pass"),
                        "global_envs": world * N, "parallelism": f"env-sharded x{world}" if multi else "single GPU",
                        "exchange": ((args.exchange + "/" + args.backend) if multi else "none")},
-            "hbm_roofline_frac_whole_step": value * alg_bytes_total(D) / (world * HBM_PEAK_GBS * 1e9),
-            "alg_bytes_per_transition": alg_bytes_total(D),
-            "roofline": {"bound": "hbm", "kernel": "obs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
+            "alg_bytes_per_transition": step_bytes,
+            "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "obs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "alg_bytes_per_launch": M * alg_bytes_obs_gather(D), "avg_launch_us": g_avg_s * 1e6,
+                         "alg_bytes_per_launch": M * dom_bytes, "avg_launch_us": g_avg_s * 1e6,
                          "launches_timed": g_n},
             "kernels_untimed_breakdown": kern,
             "off_metric": {"insert_s": t_insert, "perm_host_fisher_yates_s": t_perm},
@@ -257,7 +275,7 @@ def main():
                     out["roofline"]["traffic_source"] = tf.get("source")
             except Exception:
                 pass
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not gae_only:
             out["cpu_baseline"] = cpu_baseline(T, D, K)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
