@@ -179,6 +179,10 @@ int ppo_xp_pass_stats_host(ppo_xp *h, float *mean_std_out, size_t k);
  * itself calls ncclAllReduce on `nccl_comm` (a ncclComm_t created by the caller) between
  * the two halves. */
 int ppo_xp_set_exchange(ppo_xp *h, int mode, void *nccl_comm);
+/* The name SURVEY.md 8(b) gives this step: attach a ncclComm_t of `world` ranks (this process is
+ * `rank`) = ppo_xp_set_exchange(h, 1, nccl_comm); a NULL communicator or world <= 1 detaches
+ * (mode 0).  rank outside [0, world) => PPO_XP_EINVAL. */
+int ppo_xp_attach_comm(ppo_xp *h, void *nccl_comm, int rank, int world);
 double *ppo_xp_pass_sums_device(ppo_xp *h); /* [K][3] f64 */
 int ppo_xp_pass_finish(ppo_xp *h);
 /* RCCL bootstrap helpers for mode 1 (thin wrappers over ncclGetUniqueId / ncclCommInitRank /

@@ -752,6 +752,13 @@ int ppo_xp_set_exchange(ppo_xp *h, int mode, void *nccl_comm) {
   return 0;
 }
 
+int ppo_xp_attach_comm(ppo_xp *h, void *nccl_comm, int rank, int world) {
+  if (!h) return fail(PPO_XP_EINVAL, "attach_comm: handle is NULL");
+  if (!nccl_comm || world <= 1) return ppo_xp_set_exchange(h, 0, nullptr);
+  if (rank < 0 || rank >= world) return fail(PPO_XP_EINVAL, "attach_comm: rank %d of %d", rank, world);
+  return ppo_xp_set_exchange(h, 1, nccl_comm);
+}
+
 double *ppo_xp_pass_sums_device(ppo_xp *h) { return h ? h->sums : nullptr; }
 
 int ppo_xp_rccl_unique_id(void *out128) {

@@ -45,6 +45,8 @@ def test_exchange_modes_agree_on_one_rank():
             uid = (C.c_char * 128)()
             _lib.check(L.ppo_xp_rccl_unique_id(uid))
             _lib.check(L.ppo_xp_rccl_comm_init(C.byref(comm), uid, 0, 1))
+            assert L.ppo_xp_attach_comm(buf.handle, comm, 3, 2) == _lib.EINVAL   # rank outside [0, world)
+            _lib.check(L.ppo_xp_attach_comm(buf.handle, comm, 0, 1))            # world 1: detaches (mode 0)
             buf.set_exchange(1, comm.value)
         elif mode == 2:
             buf.set_exchange(2)
