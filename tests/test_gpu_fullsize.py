@@ -71,12 +71,17 @@ def test_c2_full_oracle(oracle):
     buf.close()
 
 
-@pytest.mark.parametrize("cfg", ["TGT"])
+@pytest.mark.parametrize("cfg", ["TGT", "C3", "C5/8"])
 def test_fullsize_properties(cfg):
+    """TGT; C3 (34 GB of observations, 1-KiB rows, the multi-wave scan); the per-GPU shard of C5 on 8 GPUs."""
     import torch
     import ppo_amd
     from ppo_amd import synth
-    T, N, D, B = synth.CONFIGS[cfg]
+    if cfg == "C5/8":
+        T, N, D, B = synth.CONFIGS["C5"]
+        N, B, cfg = N // 8, B // 8, "C5"
+    else:
+        T, N, D, B = synth.CONFIGS[cfg]
     M = T * N
     buf = ppo_amd.ExperienceBuffer(N, D, T)
     r = device_fill(buf, T, N, D, synth.SEEDS[cfg])
@@ -107,6 +112,8 @@ def test_fullsize_properties(cfg):
         n += 1
     assert n == M // B
     buf.close()
+    del r, obs, streams, ret, adv, want, perm, it, b
+    torch.cuda.empty_cache()
 
 
 def test_c4_long_horizon_assoc_vs_sequential():
