@@ -16,3 +16,13 @@ def test_cpp_reference_cases():
     print(r.stdout, r.stderr)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all reference cases passed" in r.stdout
+
+
+def test_cpp_abi_stress():
+    """tests/cpp/abi_stress.cpp: every entry point, several handles, error returns, from compiled code."""
+    exe = os.path.join(ROOT, "tests", "cpp", "abi_stress")
+    assert os.path.exists(exe), "run __graft_entry__.build() (make -C tests/cpp)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi stress passed" in r.stdout
