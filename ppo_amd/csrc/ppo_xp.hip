@@ -374,8 +374,8 @@ int pass_finish_impl(ppo_xp *h) {
   return launch_check("normalize_kernel");
 }
 
-// perm already in h->perm (device).
-int pass_begin_impl(ppo_xp *h, size_t B) {
+// perm already in h->perm_cur (device).
+int pass_begin_body(ppo_xp *h, size_t B) {
   const size_t len = buf_len(h), M = len * h->N;
   if (!h->have_returns || h->ret_len != len)
     return fail(PPO_XP_ESTATE, "pass_begin: call ppo_xp_returns() first (ExperienceBatcher::new takes the returns, data.rs:27)");
@@ -423,6 +423,14 @@ int pass_begin_impl(ppo_xp *h, size_t B) {
   int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
   if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
   return pass_finish_impl(h);
+}
+
+// A pass that failed half-way (allocation, launch, all-reduce) must not hand out minibatches.
+int pass_begin_impl(ppo_xp *h, size_t B) {
+  h->pass_active = false; h->pass_pending_finish = false;
+  const int rc = pass_begin_body(h, B);
+  if (rc) { h->pass_active = false; h->pass_pending_finish = false; }
+  return rc;
 }
 
 }  // namespace
