@@ -132,6 +132,11 @@ int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, flo
  * 0 - var(returns - values) / var(returns), population variances (fp64 sums on the device; the
  * reference runs ndarray's sequential fp32 Welford).  Needs ppo_xp_returns() first; synchronises. */
 int ppo_xp_explained_variance(ppo_xp *h, float *out);
+/* The same in two halves for env-sharded jobs: sums5 = (M, sum ret, sum ret^2, sum adv, sum adv^2) of
+ * this rank, f64, to the host; the caller adds the ranks' vectors (all-reduce of 5 doubles) and
+ * ppo_xp_explained_variance_from_sums finishes with the arithmetic of ppo_xp_explained_variance. */
+int ppo_xp_explained_variance_sums(ppo_xp *h, double *sums5);
+int ppo_xp_explained_variance_from_sums(const double *sums5, float *out);
 
 /* ExperienceBuffer::training_views (buffer.rs:142-175) + the batcher's master set. */
 int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out);
@@ -205,6 +210,16 @@ int ppo_xp_rnorm_step(ppo_xp_rnorm *r, const float *rewards, const uint8_t *done
 int ppo_xp_rnorm_step_device(ppo_xp_rnorm *r, const float *rewards_dev, const float *dones_f32_dev, float *out_dev,
                              size_t n, void *stream);
 /* Running statistics (ret_rms.mean / .var / count) and, if ret_out != NULL, the n discounted returns. */
+/* Env-sharded jobs: the batch moments of running_mean_std.rs:35-43 are taken over ALL ranks' envs.
+ * step_begin updates the local returns (runner.rs:119) and leaves this rank's (count, sum, sum of
+ * squares), f64, at ppo_xp_rnorm_sums_device(); the caller all-reduces (sum) those 3 doubles over the
+ * ranks on the same stream; step_finish merges them into the running statistics (identical on every
+ * rank), normalises and masks (runner.rs:120-124).  With one rank the result is bit-identical to
+ * ppo_xp_rnorm_step_device.  No counterpart in the reference (single process). */
+int ppo_xp_rnorm_step_begin_device(ppo_xp_rnorm *r, const float *rewards_dev, size_t n, void *stream);
+double *ppo_xp_rnorm_sums_device(ppo_xp_rnorm *r);
+int ppo_xp_rnorm_step_finish_device(ppo_xp_rnorm *r, const float *rewards_dev, const float *dones_f32_dev,
+                                    float *out_dev, size_t n, void *stream);
 int ppo_xp_rnorm_state(ppo_xp_rnorm *r, float *mean, float *var, float *count, float *ret_out, size_t n);
 
 /* ---- plumbing --------------------------------------------------------------------------- */

@@ -67,6 +67,8 @@ SYMBOLS = {
     "ppo_xp_pass_begin_device": (_i, [_vp, _sz, _vp]),
     "ppo_xp_pass_begin_device_shuffle": (_i, [_vp, _sz, _u64]),
     "ppo_xp_explained_variance": (_i, [_vp, C.POINTER(C.c_float)]),
+    "ppo_xp_explained_variance_sums": (_i, [_vp, C.POINTER(C.c_double)]),
+    "ppo_xp_explained_variance_from_sums": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "ppo_xp_pass_next": (_i, [_vp, C.POINTER(BatchView)]),
     "ppo_xp_pass_num_batches": (_sz, [_vp]),
     "ppo_xp_pass_perm_device": (_vp, [_vp]),
@@ -83,6 +85,9 @@ SYMBOLS = {
     "ppo_xp_rnorm_destroy": (None, [_vp]),
     "ppo_xp_rnorm_step": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "ppo_xp_rnorm_step_device": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "ppo_xp_rnorm_step_begin_device": (_i, [_vp, _vp, _sz, _vp]),
+    "ppo_xp_rnorm_sums_device": (_vp, [_vp]),
+    "ppo_xp_rnorm_step_finish_device": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "ppo_xp_rnorm_state": (_i, [_vp, C.POINTER(_f), C.POINTER(_f), C.POINTER(_f), _vp, _sz]),
     "ppo_xp_stream": (_vp, [_vp]),
     "ppo_xp_set_stream": (_i, [_vp, _vp]),

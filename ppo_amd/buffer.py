@@ -192,6 +192,13 @@ class ExperienceBuffer:
         check(self._L.ppo_xp_explained_variance(self._h, C.byref(out)))
         return out.value
 
+    def explained_variance_sums(self) -> np.ndarray:
+        """This rank's (M, sum ret, sum ret^2, sum adv, sum adv^2) in f64: what an env-sharded job adds up
+        over the ranks before sharded.explained_variance finishes the formula."""
+        out = np.zeros(5, np.float64)
+        check(self._L.ppo_xp_explained_variance_sums(self._h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def advantages(self):
         """`returns - values` of ExperienceBatcher::new (data.rs:62), device view [M]."""
         import torch

@@ -675,29 +675,44 @@ int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed
 
 // explained_variance (training.rs:88-99): 0 - var(returns - values) / var(returns), ddof 0; the
 // reference's guard compares the target variance with -1.0 (never true) and is kept as it is.
-int ppo_xp_explained_variance(ppo_xp *h, float *out) {
-  if (!h || !out) return fail(PPO_XP_EINVAL, "explained_variance: NULL argument");
+int ppo_xp_explained_variance_sums(ppo_xp *h, double *sums5) {
+  if (!h || !sums5) return fail(PPO_XP_EINVAL, "explained_variance: NULL argument");
   const size_t len = buf_len(h), M = len * h->N;
   if (!h->have_returns || h->ret_len != len) return fail(PPO_XP_ESTATE, "explained_variance: call ppo_xp_returns() first");
   HIP_TRY(hipSetDevice(h->device));
   constexpr unsigned kBlocks = 2048;
   if (!h->moments) { if (int rc = dev_alloc(&h->moments, 4 * (size_t)kBlocks, true)) return rc; }
-  if (M == 0) { *out = __builtin_nanf(""); return 0; }        // var of nothing = 0/0
+  for (int k = 0; k < 5; ++k) sums5[k] = 0.0;
+  if (M == 0) return 0;
   hipLaunchKernelGGL(moments_kernel, dim3(kBlocks), dim3(256), 0, h->stream, h->returns, h->adv, M, h->moments);
   if (int rc = launch_check("moments_kernel")) return rc;
   std::vector<double> part(4 * (size_t)kBlocks);
   HIP_TRY(hipMemcpyAsync(part.data(), h->moments, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  double s[4] = {0, 0, 0, 0};
-  for (unsigned b = 0; b < kBlocks; ++b) for (int k = 0; k < 4; ++k) s[k] += part[4 * (size_t)b + k];
-  const double n = (double)M;
-  const double mr = s[0] / n, ma = s[2] / n;
-  double vr = (s[1] - s[0] * mr) / n, va = (s[3] - s[2] * ma) / n;
-  if (vr < 0) vr = 0; if (va < 0) va = 0;
+  sums5[0] = (double)M;
+  for (unsigned b = 0; b < kBlocks; ++b) for (int k = 0; k < 4; ++k) sums5[1 + k] += part[4 * (size_t)b + k];
+  return 0;
+}
+
+int ppo_xp_explained_variance_from_sums(const double *s, float *out) {
+  if (!s || !out) return fail(PPO_XP_EINVAL, "explained_variance: NULL argument");
+  const double n = s[0];
+  if (!(n > 0)) { *out = __builtin_nanf(""); return 0; }         // var of nothing = 0/0
+  const double mr = s[1] / n, ma = s[3] / n;
+  double vr = (s[2] - s[1] * mr) / n, va = (s[4] - s[3] * ma) / n;
+  if (vr < 0) vr = 0;
+  if (va < 0) va = 0;
   const float target_variance = (float)vr, diff_variance = (float)va;
   if (target_variance == -1.0f) *out = __builtin_nanf("");        // training.rs:92 (sic)
   else *out = 0.0f - (diff_variance / target_variance);           // training.rs:97
   return 0;
+}
+
+int ppo_xp_explained_variance(ppo_xp *h, float *out) {
+  if (!h || !out) return fail(PPO_XP_EINVAL, "explained_variance: NULL argument");
+  double sums5[5];
+  if (int rc = ppo_xp_explained_variance_sums(h, sums5)) return rc;
+  return ppo_xp_explained_variance_from_sums(sums5, out);
 }
 
 int ppo_xp_pass_finish(ppo_xp *h) {

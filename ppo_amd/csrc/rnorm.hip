@@ -53,26 +53,44 @@ __global__ __launch_bounds__(256) void rnorm_accumulate_kernel(float *__restrict
                                         (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
 }
 
-// extra[0..2] (optional, sharded jobs): (count, sum, sumsq) of the OTHER ranks' envs, already reduced.
-__global__ __launch_bounds__(256) void rnorm_apply_kernel(float *__restrict__ ret, const float *__restrict__ rews,
-                                                          const float *__restrict__ dones, float *__restrict__ out,
-                                                          const double2 *__restrict__ partials, unsigned nparts,
-                                                          const RmsState *__restrict__ cur, RmsState *__restrict__ next,
-                                                          const double *__restrict__ extra, unsigned N, float epsilon,
-                                                          float cliprew) {
-  __shared__ double red[4][2];
-  __shared__ float s_var;
+// Fixed-order fold of the per-block partials by one 256-thread workgroup; the result is valid in
+// thread 0.  Every workgroup that calls it gets the same bits.
+__device__ __forceinline__ void fold_partials(const double2 *__restrict__ partials, unsigned nparts,
+                                              double (*red)[2], double &t1, double &t2) {
   double s1 = 0.0, s2 = 0.0;
   for (unsigned i = threadIdx.x; i < nparts; i += 256u) { const double2 p = partials[i]; s1 += p.x; s2 += p.y; }
   s1 = wsum(s1); s2 = wsum(s2);
   const unsigned w = threadIdx.x >> 6;
   if ((threadIdx.x & 63u) == 0) { red[w][0] = s1; red[w][1] = s2; }
   __syncthreads();
+  t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+}
+
+// Sharded jobs: this rank's (count, sum, sum of squares) of the updated returns, for the all-reduce.
+__global__ __launch_bounds__(256) void rnorm_fold_kernel(const double2 *__restrict__ partials, unsigned nparts,
+                                                         double *__restrict__ sums, unsigned N) {
+  __shared__ double red[4][2];
+  double t1, t2;
+  fold_partials(partials, nparts, red, t1, t2);
+  if (threadIdx.x == 0) { sums[0] = (double)N; sums[1] = t1; sums[2] = t2; }
+}
+
+// global (optional, sharded jobs): (count, sum, sumsq) over ALL ranks' envs, already all-reduced; the
+// local partials are then not read.
+__global__ __launch_bounds__(256) void rnorm_apply_kernel(float *__restrict__ ret, const float *__restrict__ rews,
+                                                          const float *__restrict__ dones, float *__restrict__ out,
+                                                          const double2 *__restrict__ partials, unsigned nparts,
+                                                          const RmsState *__restrict__ cur, RmsState *__restrict__ next,
+                                                          const double *__restrict__ global, unsigned N, float epsilon,
+                                                          float cliprew) {
+  __shared__ double red[4][2];
+  __shared__ float s_var;
+  double t1 = 0.0, t2 = 0.0;
+  if (!global) fold_partials(partials, nparts, red, t1, t2);   // kernel-uniform
   if (threadIdx.x == 0) {
-    double t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-    double t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
     double n = (double)N;
-    if (extra) { n += extra[0]; t1 += extra[1]; t2 += extra[2]; }
+    if (global) { n = global[0]; t1 = global[1]; t2 = global[2]; }
     const double bm = t1 / n;
     double bv = (t2 - t1 * bm) / n;
     bv = bv > 0.0 ? bv : 0.0;
@@ -109,8 +127,11 @@ struct ppo_xp_rnorm {
   float *ret = nullptr, *rews = nullptr, *dones = nullptr, *out = nullptr;   // [N]; rews/dones/out: staging for the host entry point
   double2 *partials = nullptr; unsigned nparts = 0;
   RmsState *state = nullptr;   // two slots
+  double *sums = nullptr;      // [3] this rank's (count, sum, sumsq); all-reduced in place by the caller (sharded jobs)
   int cur = 0;
+  bool pending = false;        // step_begin done, step_finish not yet
   hipStream_t stream = nullptr;
+  hipEvent_t done = nullptr;   // recorded after the last launch of every step, on whichever stream ran it
 };
 
 #define HIP_TRY(expr)                                                                               \
@@ -144,9 +165,11 @@ int ppo_xp_rnorm_create(ppo_xp_rnorm **out, int device, size_t num_envs, float g
   if (e == hipSuccess) e = hipMalloc((void **)&r->out, fb);
   if (e == hipSuccess) e = hipMalloc((void **)&r->partials, r->nparts * sizeof(double2));
   if (e == hipSuccess) e = hipMalloc((void **)&r->state, sizeof(init));
+  if (e == hipSuccess) e = hipMalloc((void **)&r->sums, 3 * sizeof(double));
   if (e == hipSuccess) e = hipMemset(r->ret, 0, fb);                                 // runner.rs:63
   if (e == hipSuccess) e = hipMemcpy(r->state, init, sizeof(init), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&r->done, hipEventDisableTiming);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) { ppo_xp_rnorm_destroy(r); return ppoxp_fail(PPO_XP_EIO, "rnorm_create: %s", hipGetErrorString(e)); }
   *out = r;
@@ -156,9 +179,10 @@ int ppo_xp_rnorm_create(ppo_xp_rnorm **out, int device, size_t num_envs, float g
 void ppo_xp_rnorm_destroy(ppo_xp_rnorm *r) {
   if (!r) return;
   (void)hipSetDevice(r->device);
+  if (r->done) { (void)hipEventSynchronize(r->done); (void)hipEventDestroy(r->done); }
   if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
   (void)hipFree(r->ret); (void)hipFree(r->rews); (void)hipFree(r->dones); (void)hipFree(r->out);
-  (void)hipFree(r->partials); (void)hipFree(r->state);
+  (void)hipFree(r->partials); (void)hipFree(r->state); (void)hipFree(r->sums);
   delete r;
 }
 
@@ -166,6 +190,7 @@ int ppo_xp_rnorm_step_device(ppo_xp_rnorm *r, const float *rewards_dev, const fl
                              size_t n, void *stream) {
   if (!r || !rewards_dev || !dones_f32_dev || !out_dev) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_step: NULL argument");
   if (n != r->N) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_step: %zu rewards for %zu envs", n, r->N);
+  if (r->pending) return ppoxp_fail(PPO_XP_ESTATE, "rnorm_step: a sharded step is open (call ppo_xp_rnorm_step_finish_device)");
   HIP_TRY(hipSetDevice(r->device));
   hipStream_t s = stream ? (hipStream_t)stream : r->stream;
   const unsigned N = (unsigned)r->N;
@@ -175,7 +200,44 @@ int ppo_xp_rnorm_step_device(ppo_xp_rnorm *r, const float *rewards_dev, const fl
                      r->epsilon, r->cliprew);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return ppoxp_fail(PPO_XP_EIO, "rnorm_step: launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(r->done, s));
   r->cur ^= 1;
+  return 0;
+}
+
+int ppo_xp_rnorm_step_begin_device(ppo_xp_rnorm *r, const float *rewards_dev, size_t n, void *stream) {
+  if (!r || !rewards_dev) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_step_begin: NULL argument");
+  if (n != r->N) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_step_begin: %zu rewards for %zu envs", n, r->N);
+  if (r->pending) return ppoxp_fail(PPO_XP_ESTATE, "rnorm_step_begin: the previous sharded step was not finished");
+  HIP_TRY(hipSetDevice(r->device));
+  hipStream_t s = stream ? (hipStream_t)stream : r->stream;
+  const unsigned N = (unsigned)r->N;
+  hipLaunchKernelGGL(rnorm_accumulate_kernel, dim3(r->nparts), dim3(256), 0, s, r->ret, rewards_dev, r->partials, N, r->gamma);
+  hipLaunchKernelGGL(rnorm_fold_kernel, dim3(1), dim3(256), 0, s, r->partials, r->nparts, r->sums, N);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ppoxp_fail(PPO_XP_EIO, "rnorm_step_begin: launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(r->done, s));
+  r->pending = true;
+  return 0;
+}
+
+double *ppo_xp_rnorm_sums_device(ppo_xp_rnorm *r) { return r ? r->sums : nullptr; }
+
+int ppo_xp_rnorm_step_finish_device(ppo_xp_rnorm *r, const float *rewards_dev, const float *dones_f32_dev, float *out_dev,
+                                    size_t n, void *stream) {
+  if (!r || !rewards_dev || !dones_f32_dev || !out_dev) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_step_finish: NULL argument");
+  if (n != r->N) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_step_finish: %zu rewards for %zu envs", n, r->N);
+  if (!r->pending) return ppoxp_fail(PPO_XP_ESTATE, "rnorm_step_finish: no sharded step is open");
+  HIP_TRY(hipSetDevice(r->device));
+  hipStream_t s = stream ? (hipStream_t)stream : r->stream;
+  hipLaunchKernelGGL(rnorm_apply_kernel, dim3(r->nparts), dim3(256), 0, s, r->ret, rewards_dev, dones_f32_dev, out_dev,
+                     r->partials, r->nparts, r->state + r->cur, r->state + (r->cur ^ 1), (const double *)r->sums,
+                     (unsigned)r->N, r->epsilon, r->cliprew);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return ppoxp_fail(PPO_XP_EIO, "rnorm_step_finish: launch failed: %s", hipGetErrorString(e));
+  HIP_TRY(hipEventRecord(r->done, s));
+  r->cur ^= 1;
+  r->pending = false;
   return 0;
 }
 
@@ -196,6 +258,7 @@ int ppo_xp_rnorm_step(ppo_xp_rnorm *r, const float *rewards, const uint8_t *done
 int ppo_xp_rnorm_state(ppo_xp_rnorm *r, float *mean, float *var, float *count, float *ret_out, size_t n) {
   if (!r) return ppoxp_fail(PPO_XP_EINVAL, "rnorm_state: handle is NULL");
   HIP_TRY(hipSetDevice(r->device));
+  HIP_TRY(hipEventSynchronize(r->done));   // a caller's stream may have run the last step
   HIP_TRY(hipStreamSynchronize(r->stream));
   RmsState st;
   HIP_TRY(hipMemcpy(&st, r->state + r->cur, sizeof(st), hipMemcpyDeviceToHost));

@@ -55,6 +55,34 @@ class RewardNormalizer:
         check(self._L.ppo_xp_rnorm_step(self._h, p(r), p(d), p(out), self.num_envs))
         return out
 
+    def normalized_rewards_sharded(self, rewards, dones, all_reduce):
+        """runner.rs:114-127 for one rank of an env-sharded job: the batch moments (running_mean_std.rs:35-43)
+        are over all ranks' envs.  rewards / dones: CUDA f32 tensors of this rank's envs; `all_reduce(t)`
+        sums the 3-double CUDA tensor `t` in place over the ranks (sharded.ShardedRewardNormalizer wires it
+        to torch.distributed).  Runs on torch's current stream."""
+        import torch
+        from .buffer import device_tensor
+        if not (hasattr(rewards, "is_cuda") and rewards.is_cuda) or rewards.shape != (self.num_envs,) \
+                or dones.shape != (self.num_envs,) or rewards.dtype != torch.float32 or dones.dtype != torch.float32 \
+                or not (rewards.is_contiguous() and dones.is_contiguous()):
+            raise PpoXpPanic(_lib.EINVAL, "normalized_rewards_sharded: contiguous f32 CUDA tensors of NUM_ENVS expected")
+        ts = torch.cuda.current_stream(self.device)
+        if ts.cuda_stream == 0:
+            ts.synchronize()      # NULL = "the object's own stream" in the ABI: order it after the producers by hand
+        stream = C.c_void_p(ts.cuda_stream)
+        out = torch.empty_like(rewards)
+        check(self._L.ppo_xp_rnorm_step_begin_device(self._h, C.c_void_p(rewards.data_ptr()), self.num_envs, stream))
+        sums = device_tensor(self._L.ppo_xp_rnorm_sums_device(self._h), (3,), torch.float64, self.device, self)
+        if ts.cuda_stream == 0:
+            self.state()          # the object's stream has produced the sums
+        all_reduce(sums)
+        if ts.cuda_stream == 0:
+            ts.synchronize()      # the collective is ordered with torch's stream, not with the object's own
+        check(self._L.ppo_xp_rnorm_step_finish_device(self._h, C.c_void_p(rewards.data_ptr()), C.c_void_p(dones.data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), self.num_envs, stream))
+        self.state()              # synchronises whichever stream ran the step
+        return out
+
     def state(self):
         """(ret_rms.mean, ret_rms.var, count, ret[N])."""
         m, v, c = C.c_float(), C.c_float(), C.c_float()

@@ -126,3 +126,55 @@ class ShardedBatcher:
 
     def __iter__(self):
         return self.into_iter()
+
+
+def _all_reduce_f64(dist, t, group):
+    """Sum a small f64 tensor over the ranks in place; gloo (tests) goes through the host."""
+    import torch
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        torch.cuda.current_stream(t.device).synchronize()
+        host = t.cpu()
+        dist.all_reduce(host, group=group)
+        t.copy_(host)
+        torch.cuda.current_stream(t.device).synchronize()
+    else:
+        dist.all_reduce(t, group=group)
+
+
+def explained_variance(buffer: ExperienceBuffer, group=None) -> float:
+    """explained_variance(values, returns) (ppo/src/training.rs:88-99) over ALL ranks' transitions: every
+    rank contributes five f64 sums, one all-reduce, the same closing arithmetic as on one GPU."""
+    import torch
+    import torch.distributed as dist
+    sums = torch.from_numpy(buffer.explained_variance_sums())
+    if dist.get_backend(group) == "nccl":
+        dev = sums.to(f"cuda:{buffer.device}")
+        dist.all_reduce(dev, group=group)
+        sums = dev.cpu()
+    else:
+        dist.all_reduce(sums, group=group)
+    s = np.ascontiguousarray(sums.numpy(), np.float64)
+    out = C.c_float()
+    check(_lib.load().ppo_xp_explained_variance_from_sums(s.ctypes.data_as(C.POINTER(C.c_double)), C.byref(out)))
+    return out.value
+
+
+class ShardedRewardNormalizer:
+    """RewardNormalizer (ppo/src/common/runner.rs:114-127) for one rank of an env-sharded job: local
+    discounted returns, ONE all-reduce of (count, sum, sum of squares) per step, identical running
+    statistics on every rank."""
+
+    def __init__(self, num_local_envs: int, group=None, **kw):
+        import torch.distributed as dist
+        from .runner import RewardNormalizer
+        self.dist, self.group = dist, group
+        self.inner = RewardNormalizer(num_local_envs, **kw)
+
+    def normalized_rewards(self, rewards, dones):
+        return self.inner.normalized_rewards_sharded(rewards, dones, lambda t: _all_reduce_f64(self.dist, t, self.group))
+
+    def state(self):
+        return self.inner.state()
+
+    def close(self):
+        self.inner.close()

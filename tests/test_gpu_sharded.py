@@ -111,6 +111,23 @@ def _rank(rank, world, port, T, N, D, B, seed, q):
             off = rank * Bl
             worst = max(worst, float(np.abs(got - want64[off:off + Bl]).max()))
             assert np.abs(got - want32[off:off + Bl]).max() < 2e-5
+        # explained_variance over all ranks' transitions (training.rs:88-99) == the oracle's on the full arrays
+        ev = sharded.explained_variance(buf)
+        ev64 = O.explained_variance_f64(full["values"].reshape(-1), ret_full.reshape(-1))
+        assert abs(ev - ev64) < 2e-6 * max(1.0, abs(ev64)), (ev, ev64)
+        # reward normaliser (runner.rs:114-127): batch moments over ALL envs, same running statistics on every rank
+        rn = sharded.ShardedRewardNormalizer(n)
+        orn = O.OracleRewardNormalizer(N)
+        for t in range(6):
+            want = orn.normalized_rewards(full["rewards"][t], full["dones"][t])
+            got = rn.normalized_rewards(torch.from_numpy(np.ascontiguousarray(full["rewards"][t, sl])).cuda(),
+                                        torch.from_numpy(np.ascontiguousarray(full["dones"][t, sl]).astype(np.float32)).cuda())
+            assert np.abs(got.cpu().numpy() - want[sl]).max() < 2e-5
+        m, v, c, ret_state = rn.state()
+        om, ov, oc, oret = orn.state()
+        assert abs(m - om) < 2e-5 and abs(v - ov) < 2e-5 * max(1.0, ov) and c == oc
+        assert np.array_equal(ret_state.view(np.uint32), np.ascontiguousarray(oret[sl]).view(np.uint32))
+        rn.close()
         buf.close()
         q.put((rank, worst))
     finally:
@@ -130,3 +147,35 @@ def test_two_ranks_on_one_gpu_over_gloo():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=5) for _ in range(2))
     assert [r[0] for r in res] == [0, 1] and max(r[1] for r in res) < 2e-6
+
+
+def test_sharded_halves_equal_whole_on_one_rank():
+    """begin / (no-op all-reduce) / finish of the reward normaliser and sums / from_sums of
+    explained_variance are bit-identical to the one-call entry points."""
+    import torch
+    import ppo_amd
+    from ppo_amd import _lib, synth
+    N = 700
+    r = synth.rollout(8, N, 2, 5, 0.1)
+    a, b = ppo_amd.RewardNormalizer(N), ppo_amd.RewardNormalizer(N)
+    for t in range(8):
+        rw = torch.from_numpy(r["rewards"][t]).cuda()
+        dn = torch.from_numpy(r["dones"][t].astype(np.float32)).cuda()
+        x = a.normalized_rewards(rw, dn)
+        y = b.normalized_rewards_sharded(rw, dn, lambda sums: None)
+        assert torch.equal(x.view(torch.int32), y.view(torch.int32))
+    assert a.state()[:3] == b.state()[:3]
+    L = _lib.load()
+    with pytest.raises(ppo_amd.PpoXpError):      # finish without begin
+        _lib.check(L.ppo_xp_rnorm_step_finish_device(b._h, C.c_void_p(rw.data_ptr()), C.c_void_p(dn.data_ptr()),
+                                                     C.c_void_p(x.data_ptr()), N, None))
+    a.close(); b.close()
+    buf = ppo_amd.ExperienceBuffer(N, 2, 8)
+    _fill(buf, r)
+    buf.returns(r["last_dones"])
+    s5 = buf.explained_variance_sums()
+    assert s5[0] == 8 * N
+    out = C.c_float()
+    _lib.check(L.ppo_xp_explained_variance_from_sums(s5.ctypes.data_as(C.POINTER(C.c_double)), C.byref(out)))
+    assert np.float32(out.value).view(np.uint32) == np.float32(buf.explained_variance()).view(np.uint32)
+    buf.close()
