@@ -148,6 +148,9 @@ int main() {
   REQUIRE(ppo_xp_returns(h, r.last_dones.data(), N, PPO_XP_GAE_NO_PACK, nullptr) == 0);  // records built lazily by the pass
   float ev = 0.f;
   REQUIRE(ppo_xp_explained_variance(h, &ev) == 0 && ev <= 0.f);              // training.rs:97: 0 - ratio
+  double s5[5]; float ev2 = 1.f;
+  REQUIRE(ppo_xp_explained_variance_sums(h, s5) == 0 && s5[0] == (double)(cap * N));
+  REQUIRE(ppo_xp_explained_variance_from_sums(s5, &ev2) == 0 && ev2 == ev);  // the two halves of the same call
 
   // ---- passes: profiling on, every way to start one ------------------------------------------
   const size_t M = cap * N;
@@ -210,8 +213,20 @@ int main() {
     for (float x : out) REQUIRE(std::fabs(x) <= 10.f);
   }
   REQUIRE(ppo_xp_rnorm_step(rn, r.rewards.data(), r.dones.data(), out.data(), N - 1) == PPO_XP_EINVAL);
+  float *d_rew = nullptr, *d_done = nullptr, *d_out = nullptr;              // the sharded halves (here: one rank)
+  REQUIRE(hipMalloc((void **)&d_rew, N * 4) == hipSuccess && hipMalloc((void **)&d_done, N * 4) == hipSuccess &&
+          hipMalloc((void **)&d_out, N * 4) == hipSuccess);
+  REQUIRE(hipMemcpy(d_rew, r.rewards.data(), N * 4, hipMemcpyHostToDevice) == hipSuccess);
+  REQUIRE(hipMemset(d_done, 0, N * 4) == hipSuccess);
+  REQUIRE(ppo_xp_rnorm_step_finish_device(rn, d_rew, d_done, d_out, N, nullptr) == PPO_XP_ESTATE);
+  REQUIRE(ppo_xp_rnorm_step_begin_device(rn, d_rew, N, nullptr) == 0);
+  REQUIRE(ppo_xp_rnorm_step_device(rn, d_rew, d_done, d_out, N, nullptr) == PPO_XP_ESTATE);
+  REQUIRE(ppo_xp_rnorm_step_begin_device(rn, d_rew, N, nullptr) == PPO_XP_ESTATE);
+  REQUIRE(ppo_xp_rnorm_sums_device(rn) != nullptr);
+  REQUIRE(ppo_xp_rnorm_step_finish_device(rn, d_rew, d_done, d_out, N, nullptr) == 0);
   float mean, var, count;
-  REQUIRE(ppo_xp_rnorm_state(rn, &mean, &var, &count, st.data(), N) == 0 && count > 4.f * N - 1.f);
+  REQUIRE(ppo_xp_rnorm_state(rn, &mean, &var, &count, st.data(), N) == 0 && count > 5.f * N - 1.f);
+  REQUIRE(hipFree(d_rew) == hipSuccess && hipFree(d_done) == hipSuccess && hipFree(d_out) == hipSuccess);
   ppo_xp_rnorm_destroy(rn);
 
   ppo_xp_destroy(h2);
