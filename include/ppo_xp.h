@@ -240,7 +240,8 @@ int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launc
 const char *ppo_xp_kernel_name(int kernel_id);
 
 /* Tunables (A/B measurements in one process; results never depend on them except through the
- * documented tolerance of PPO_XP_GAE_ASSOC): "gather_nt" 0/1, "gather_block" 64/256, "gather_xcd" 0/1/2,
+ * documented tolerance of PPO_XP_GAE_ASSOC): "gather_nt" 0/1, "gather_block" 64/256, "gather_xcd" 0/1/2, "fold_tiles" 0..65536 (single-GPU passes with at most this many 256-row tiles per
+ * minibatch skip the finalize launch: the standardise workgroups add the tile sums themselves),
  * "gae_waves" 0 (auto)/1/2/4/8/16 (waves per 64 envs of the sequential scan), "gae_unroll" 0 (auto)/4/8/16,
  * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams).
  * Unknown names or values => PPO_XP_EINVAL. */

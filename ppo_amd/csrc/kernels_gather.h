@@ -149,16 +149,15 @@ __global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) 
   }
 }
 
-// Fixed-order reduction of the tile partials of minibatch k -> sums[k] = (count, sum, sumsq).
-// grid = K, block = 256.  Deterministic: the tree shape depends only on tiles_per_mb.
-__global__ __launch_bounds__(256) void finalize_stats_kernel(const double2 *__restrict__ partials,
-                                                             double *__restrict__ sums, unsigned tiles_per_mb,
-                                                             size_t B) {
-  __shared__ double s1s[256], s2s[256];
-  const unsigned k = blockIdx.x;
+// Fixed-order reduction of the tile partials of one minibatch by a 256-thread workgroup; the result is
+// valid in every thread after the call.  Deterministic: the tree shape depends only on tiles_per_mb, so
+// every workgroup that runs it (finalize_stats_kernel, or each normalize workgroup when it folds the
+// partials itself) gets the same bits.
+__device__ __forceinline__ void reduce_partials(const double2 *__restrict__ partials, unsigned tiles_per_mb,
+                                                double *s1s, double *s2s, double &t1, double &t2) {
   double s1 = 0.0, s2 = 0.0;
   for (unsigned i = threadIdx.x; i < tiles_per_mb; i += 256u) {
-    double2 p = partials[(size_t)k * tiles_per_mb + i];
+    double2 p = partials[i];
     s1 += p.x; s2 += p.y;
   }
   s1s[threadIdx.x] = s1; s2s[threadIdx.x] = s2;
@@ -167,10 +166,23 @@ __global__ __launch_bounds__(256) void finalize_stats_kernel(const double2 *__re
     if (threadIdx.x < off) { s1s[threadIdx.x] += s1s[threadIdx.x + off]; s2s[threadIdx.x] += s2s[threadIdx.x + off]; }
     __syncthreads();
   }
+  t1 = s1s[0]; t2 = s2s[0];
+}
+
+// sums[k] = (count, sum, sumsq) of minibatch k.  grid = K, block = 256.  Launched when the sums
+// themselves are needed (sharded passes: they cross the ranks) or when a minibatch has too many tiles
+// for every normalize workgroup to fold them again.
+__global__ __launch_bounds__(256) void finalize_stats_kernel(const double2 *__restrict__ partials,
+                                                             double *__restrict__ sums, unsigned tiles_per_mb,
+                                                             size_t B) {
+  __shared__ double s1s[256], s2s[256];
+  const unsigned k = blockIdx.x;
+  double t1, t2;
+  reduce_partials(partials + (size_t)k * tiles_per_mb, tiles_per_mb, s1s, s2s, t1, t2);
   if (threadIdx.x == 0) {
     sums[3 * k + 0] = (double)B;
-    sums[3 * k + 1] = s1s[0];
-    sums[3 * k + 2] = s2s[0];
+    sums[3 * k + 1] = t1;
+    sums[3 * k + 2] = t2;
   }
 }
 
@@ -190,17 +202,33 @@ __device__ __forceinline__ void stats_from_sums(const double *s, float &mean, fl
 // In-place standardisation of adv_out[k*B .. (k+1)*B).  grid = K * tiles_per_mb blocks (1-D, so K
 // is not limited by gridDim.y), tiles_per_mb = ceil(B / 1024), block = 256, four consecutive floats
 // per thread (16-byte accesses when the minibatch base allows it).
-__global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_out, const double *__restrict__ sums,
+// FOLD: no finalize_stats launch ran; every workgroup reduces the minibatch's `stat_tiles` partials
+// itself (same tree, same bits) and workgroup 0 of the minibatch also stores sums[k].
+template <bool FOLD>
+__global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_out, double *__restrict__ sums,
+                                                        const double2 *__restrict__ partials, unsigned stat_tiles,
                                                         float *__restrict__ stats, size_t B, unsigned tiles_per_mb) {
   const unsigned k = blockIdx.x / tiles_per_mb;
   const unsigned bx = blockIdx.x - k * tiles_per_mb;
-  float mean, stdv;
-  stats_from_sums(sums + 3 * (size_t)k, mean, stdv);
-  const float denom = stdv + 1e-8f;
   float *a = adv_out + (size_t)k * B;
   const size_t j = ((size_t)bx * 256u + threadIdx.x) * 4u;
-  if (j + 4 <= B && ((reinterpret_cast<uintptr_t>(a + j) & 15u) == 0)) {
-    f32x4 x = *reinterpret_cast<f32x4 *>(a + j);
+  const bool vec = j + 4 <= B && ((reinterpret_cast<uintptr_t>(a + j) & 15u) == 0);
+  f32x4 x = {0.f, 0.f, 0.f, 0.f};
+  if (FOLD && vec) x = *reinterpret_cast<f32x4 *>(a + j);     // in flight while the partials are folded
+  double s[3];
+  if (FOLD) {
+    __shared__ double s1s[256], s2s[256];
+    reduce_partials(partials + (size_t)k * stat_tiles, stat_tiles, s1s, s2s, s[1], s[2]);
+    s[0] = (double)B;
+    if (bx == 0 && threadIdx.x == 0) { sums[3 * (size_t)k] = s[0]; sums[3 * (size_t)k + 1] = s[1]; sums[3 * (size_t)k + 2] = s[2]; }
+  } else {
+    s[0] = sums[3 * (size_t)k]; s[1] = sums[3 * (size_t)k + 1]; s[2] = sums[3 * (size_t)k + 2];
+  }
+  float mean, stdv;
+  stats_from_sums(s, mean, stdv);
+  const float denom = stdv + 1e-8f;
+  if (vec) {
+    if (!FOLD) x = *reinterpret_cast<f32x4 *>(a + j);         // measured: loading first costs 2 us at TGT
     x.x = (x.x - mean) / denom; x.y = (x.y - mean) / denom; x.z = (x.z - mean) / denom; x.w = (x.w - mean) / denom;
     *reinterpret_cast<f32x4 *>(a + j) = x;
   } else {

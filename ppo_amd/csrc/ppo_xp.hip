@@ -129,7 +129,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256;
 };
 
 namespace {
@@ -362,14 +362,20 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
   return 0;
 }
 
-int pass_finish_impl(ppo_xp *h) {
+// fold = true: no finalize_stats launch preceded; the normalize workgroups reduce the partials themselves.
+int pass_finish_impl(ppo_xp *h, bool fold = false) {
   const size_t K = h->pass_K, B = h->pass_B;
   if (K == 0) { h->pass_pending_finish = false; return 0; }
   const size_t nbx = (B + 1023) / 1024;
   if (K * nbx > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for the normalize launch");
+  const unsigned stat_tiles = (unsigned)((B + 255) / 256);
   ProfScope ps(h, PPO_XP_K_NORMALIZE);
-  hipLaunchKernelGGL(normalize_kernel, dim3((unsigned)(K * nbx)), dim3(256), 0, h->stream, h->adv_out, h->sums,
-                     h->stats, B, (unsigned)nbx);
+  if (fold)
+    hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)(K * nbx)), dim3(256), 0, h->stream, h->adv_out, h->sums,
+                       h->partials, stat_tiles, h->stats, B, (unsigned)nbx);
+  else
+    hipLaunchKernelGGL(normalize_kernel<false>, dim3((unsigned)(K * nbx)), dim3(256), 0, h->stream, h->adv_out, h->sums,
+                       h->partials, stat_tiles, h->stats, B, (unsigned)nbx);
   h->pass_pending_finish = false;
   return launch_check("normalize_kernel");
 }
@@ -405,7 +411,10 @@ int pass_begin_body(ppo_xp *h, size_t B) {
     hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
     if (int rc = launch_check("scalar_gather_kernel")) return rc;
   }
-  {
+  // single GPU and few tiles per minibatch (C2: 64): the normalize workgroups fold the partials
+  // themselves and the finalize launch (4.5 us, a tenth of such a pass) is skipped
+  const bool fold = h->xmode == 0 && g.tiles_per_mb <= (unsigned)h->fold_tiles;
+  if (!fold) {
     ProfScope ps(h, PPO_XP_K_FINALIZE);
     hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
                        g.tiles_per_mb, B);
@@ -413,7 +422,7 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   }
   if (h->xmode == 0) {
     // single GPU: standardise while the raw advantages are still in L2 / Infinity Cache, rows last
-    if (int rc = pass_finish_impl(h)) return rc;
+    if (int rc = pass_finish_impl(h, fold)) return rc;
     return launch_obs_gather(h, K, B, M);
   }
   // sharded: the observation rows do not depend on the statistics; enqueue them before the
@@ -859,6 +868,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   std::string n(name);
   if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
   else if (n == "gather_block" && (value == 64 || value == 256)) h->gather_block = value;
+  else if (n == "fold_tiles" && value >= 0 && value <= 65536) h->fold_tiles = value;
   else if (n == "gather_xcd" && value >= 0 && value <= 2) h->gather_xcd = value;
   else if (n == "gae_waves" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) h->gae_waves = value;
   else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
