@@ -108,8 +108,12 @@ def check_pass(xp, oracle, g, o, last_dones, B, seed=None, perm=None, algo=0, ex
             assert np.isnan(got).all() and np.isnan(want32).all()    # 0 * inf, as the reference
             continue
         if s64 > 1e-3:
-            np.testing.assert_allclose(got, want64, rtol=0, atol=ATOL_STD64 * max(1.0, np.abs(want64).max()))
-            np.testing.assert_allclose(got, want32, rtol=0, atol=ATOL_STD * max(1.0, np.abs(want32).max()))
+            # the reference's tail is fp32: (a - fl32(mean)) / fl32(std).  Rounding the mean alone moves the
+            # result by up to 2^-24 * |mean| / std, which is not small when a minibatch is nearly constant
+            # (found by tests/test_gpu_fuzz.py: two rows 1.4054, 1.4110 -> 2e-5); it is part of the bar.
+            amp = 1.2e-7 * float(np.abs(a).max()) / s64
+            np.testing.assert_allclose(got, want64, rtol=0, atol=ATOL_STD64 * max(1.0, np.abs(want64).max()) + amp)
+            np.testing.assert_allclose(got, want32, rtol=0, atol=ATOL_STD * max(1.0, np.abs(want32).max()) + 2 * amp)
         assert abs(stats[k, 0] - m64) <= 1e-6 * max(1.0, abs(m64)) and abs(stats[k, 1] - s64) <= 1e-6 * max(1.0, s64)
 
 
