@@ -76,6 +76,49 @@ def cpu_baseline(T, D, K, target_seconds=12.0):
             "all_cores": {"value": M / min(tm), "cores": ncores}}
 
 
+def quick_measure(cfg, device, steps=200, warmup=20):
+    """Untimed-by-events whole-step rate of another BASELINE.json config on one GPU (same step as the main
+    measurement: returns() + one shuffled pass, inputs resident), reported beside the headline."""
+    import torch
+    import ppo_amd
+    from ppo_amd import _lib, synth
+    T, N, D, B = synth.CONFIGS[cfg]
+    M, K = T * N, (T * N) // B
+    buf = ppo_amd.ExperienceBuffer(N, D, T, device=device)
+    buf.use_torch_stream()
+    L, h = _lib.load(), buf.handle
+    r = synth.rollout_device(T, N, D, synth.SEEDS[cfg], torch.device("cuda", device))
+    for t in range(T):
+        buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t], r["neglogps"][t])
+    last_dones = r["last_dones"].cpu().numpy()
+    ld_p = last_dones.ctypes.data_as(C.c_void_p)
+    _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
+    _lib.check(L.ppo_xp_pass_begin(h, B, None, synth.SEEDS[cfg]))
+    perm = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, device, buf).clone()
+    bv = _lib.BatchView()
+
+    def step():
+        _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
+        _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
+        n = 0
+        while L.ppo_xp_pass_next(h, C.byref(bv)) == 0:
+            n += 1
+        assert n == K
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    buf.close()
+    value = M * steps / dt
+    return {"workload": f"{cfg}: T={T}, N={N} envs, obs_dim={D}, batch={B} (K={K})", "value": value, "unit": "transitions/s",
+            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "hbm_roofline_frac_whole_step": value * alg_bytes_total(D) / (HBM_PEAK_GBS * 1e9)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -86,6 +129,7 @@ def main():
                          "over the ranks; C4: GAE only (T=16384, N=1024)")
     ap.add_argument("--gae", default=None, choices=["seq", "assoc"], help="GAE algorithm (default: seq; assoc for C4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 line that a default one-GPU run reports beside TGT")
     ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
     ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank control flow with all ranks on one GPU")
@@ -277,13 +321,17 @@ def main():
                 pass
         if not args.no_cpu_baseline and world == 1 and not gae_only:
             out["cpu_baseline"] = cpu_baseline(T, D, K)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
-
     if comm is not None:
         buf.sync()
         L.ppo_xp_rccl_comm_destroy(comm)
     buf.close()
+    if rank == 0:
+        # BASELINE.json's configs[1] (C2) beside the headline, measured the same way (no events at all)
+        if world == 1 and not multi and args.config == "TGT" and not args.no_secondary:
+            torch.cuda.empty_cache()
+            out["also"] = {"C2": quick_measure("C2", local_rank)}
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if multi:
         dist.destroy_process_group()
 
