@@ -478,6 +478,26 @@ def test_train_loop_lifecycle(xp, oracle):
     g.close()
 
 
+def test_empty_buffer(xp, oracle):
+    """A fresh (or reset) buffer holds nothing: len 0, empty views and returns (buffer.rs:123-129,
+    187-225 with len = 0), an empty pass (data.rs:117), NaN explained variance (0/0)."""
+    g, o = xp.ExperienceBuffer(4, 3, 6), oracle.OracleBuffer(4, 3, 6)
+    for _ in range(2):
+        assert len(g) == len(o) == 0
+        ret = g.returns(np.zeros(4, np.uint8), to_host=True)
+        assert ret.shape == o.returns(np.zeros(4, np.uint8)).shape == (0,)
+        assert all(t.shape[0] == 0 for t in g.training_views())
+        batcher = xp.ExperienceBatcher(g, 2)
+        assert len(batcher) == 0 and list(batcher.into_iter(seed=1)) == []
+        assert np.isnan(g.explained_variance())
+        from ppo_amd import synth
+        r = synth.rollout(3, 4, 3, 8, 0.1)
+        fill(g, r); fill(o, r)
+        check_pass(xp, oracle, g, o, r["last_dones"], 5, seed=2)
+        g.reset_counter(); o.reset_counter()
+    g.close()
+
+
 def test_two_handles_interleaved(xp, oracle):
     """Distinct handles are independent (one per GPU / rank in the sharded job): interleaving their
     calls must not mix state, streams or scratch."""
