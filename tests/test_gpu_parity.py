@@ -376,8 +376,10 @@ def test_panics(xp):
     with pytest.raises(AssertionError):      # perm entry out of range
         xp.ExperienceBatcher(buf, 2).into_iter(perm=np.array([0, 5], np.uint32))
     assert list(xp.ExperienceBatcher(buf, 3).into_iter(seed=1)) == []   # B > M -> None (data.rs:117)
-    with pytest.raises(xp.PpoXpError):
+    with pytest.raises((xp.PpoXpError, AssertionError)):
         xp.ExperienceBuffer(0, 3, 3)
+    with pytest.raises((xp.PpoXpError, AssertionError)):      # M must fit the u32 permutation indices; refused before allocating
+        xp.ExperienceBuffer(65536, 1, 65536)
     buf.close()
 
 
