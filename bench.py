@@ -294,7 +294,7 @@ def main():
         out = {
             "metric": metric, "value": value, "unit": "transitions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.config == "C5" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"{args.config}: T={T}, N={N} envs per GPU, GAE + returns only, "
                                     f"{'associative (chunked)' if algo & 1 else 'sequential'} scan, gamma=0.99 lambda=0.95") if gae_only else
                                    (f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
