@@ -112,6 +112,13 @@ int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const siz
 int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions,
                       const float *vals, const float *dones_f32, const float *neglogps, size_t n);
 
+/* Page-locked host memory for the rows handed to ppo_xp_add / ppo_xp_add_many (hipHostMalloc /
+ * hipHostFree).  Rows that live in such memory are DMA-ed by the copy engines at PCIe rate; rows in
+ * ordinary (pageable) memory are staged by the HIP runtime at a fraction of it ("PCIe-
+ * inclusive rate").  No counterpart in the reference, whose buffer is host memory. */
+void *ppo_xp_host_alloc(size_t bytes);
+void ppo_xp_host_free(void *p);
+
 /* ExperienceBuffer::reset_counter (buffer.rs:131-133): counter = 0, data untouched. */
 void ppo_xp_reset_counter(ppo_xp *h);
 /* ExperienceBuffer::len (buffer.rs:123-129): min(counter, capacity). */

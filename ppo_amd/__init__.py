@@ -5,9 +5,9 @@ Compute lives in libppo_xp.so (hand-written HIP for gfx950, C ABI in include/ppo
 classes here mirror ppo/src/common/buffer.rs and ppo/src/model/data.rs.  There is no CPU path.
 """
 from ._lib import GAE_ASSOC, GAE_NO_PACK, GAE_SEQUENTIAL, PpoXpError, PpoXpPanic, gae_chunk
-from .buffer import ExperienceBuffer, device_tensor
+from .buffer import ExperienceBuffer, device_tensor, pinned_empty
 from .data import ExperienceBatch, ExperienceBatcher, ExperienceBatcherIterator
 from .runner import RewardNormalizer
 
 __all__ = ["ExperienceBuffer", "ExperienceBatch", "ExperienceBatcher", "ExperienceBatcherIterator", "RewardNormalizer", "PpoXpError",
-           "PpoXpPanic", "GAE_SEQUENTIAL", "GAE_ASSOC", "GAE_NO_PACK", "gae_chunk", "device_tensor"]
+           "PpoXpPanic", "GAE_SEQUENTIAL", "GAE_ASSOC", "GAE_NO_PACK", "gae_chunk", "device_tensor", "pinned_empty"]

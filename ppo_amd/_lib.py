@@ -76,6 +76,8 @@ SYMBOLS = {
     "ppo_xp_pass_stats_host": (_i, [_vp, _vp, _sz]),
     "ppo_xp_set_exchange": (_i, [_vp, _i, _vp]),
     "ppo_xp_attach_comm": (_i, [_vp, _vp, _i, _i]),
+    "ppo_xp_host_alloc": (_vp, [_sz]),
+    "ppo_xp_host_free": (None, [_vp]),
     "ppo_xp_pass_sums_device": (_vp, [_vp]),
     "ppo_xp_pass_finish": (_i, [_vp]),
     "ppo_xp_rccl_unique_id": (_i, [_vp]),

@@ -37,6 +37,33 @@ class _DevArray:
         self._owner = owner  # keeps the handle alive
 
 
+class _Pinned:
+    """Owner of one ppo_xp_host_alloc block; frees it when the last numpy view is gone."""
+
+    def __init__(self, nbytes):
+        self._L = _lib.load()
+        self.ptr = self._L.ppo_xp_host_alloc(nbytes)
+        if not self.ptr:
+            raise _lib.PpoXpError(_lib.ENOMEM, "pinned host allocation failed")
+
+    def __del__(self):
+        try:
+            self._L.ppo_xp_host_free(C.c_void_p(self.ptr))
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """numpy array in page-locked host memory (ppo_xp_host_alloc): rows handed to add_experience /
+    add_many from such arrays cross PCIe by DMA instead of being staged by the runtime."""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    owner = _Pinned(max(n * dtype.itemsize, 1))
+    buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(owner.ptr)
+    buf._ppo_owner = owner                      # the ctypes object keeps the block alive for its views
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+
+
 def device_tensor(ptr, shape, dtype, device_index, owner=None):
     """torch view of `shape` elements of `dtype` at device pointer `ptr` (no copy)."""
     import torch

@@ -588,6 +588,17 @@ int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const i
   return 0;
 }
 
+void *ppo_xp_host_alloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)fail(PPO_XP_ENOMEM, "host_alloc: hipHostMalloc(%zu) failed", bytes);
+    return nullptr;
+  }
+  return p;
+}
+
+void ppo_xp_host_free(void *p) { if (p) (void)hipHostFree(p); }
+
 void ppo_xp_reset_counter(ppo_xp *h) {                          // buffer.rs:131-133
   if (!h) return;
   h->counter = 0; h->have_returns = false; h->have_rec = false; h->pass_active = false;

@@ -480,6 +480,25 @@ def test_train_loop_lifecycle(xp, oracle):
     g.close()
 
 
+def test_pinned_host_rows(xp, oracle):
+    """Rows handed over in page-locked memory (ppo_xp_host_alloc) give the same buffer as ordinary arrays."""
+    from ppo_amd import synth
+    T, N, D = 6, 40, 8
+    r = synth.rollout(T, N, D, 99, 0.1)
+    pin = {k: xp.pinned_empty(v.shape, v.dtype) for k, v in r.items()}
+    for k in r:
+        pin[k][...] = r[k]
+    g, o = xp.ExperienceBuffer(N, D, T), oracle.OracleBuffer(N, D, T)
+    g.add_many(pin["obs"], pin["rewards"], pin["actions"], pin["values"], pin["dones"], pin["neglogps"])
+    fill(o, r)
+    check_pass(xp, oracle, g, o, pin["last_dones"], 50, seed=3)
+    g.reset_counter(); o.reset_counter()
+    fill(g, pin); fill(o, r)                      # add_experience, row by row, from pinned rows
+    check_pass(xp, oracle, g, o, r["last_dones"], 50, seed=4)
+    g.close()
+    del pin
+
+
 def test_empty_buffer(xp, oracle):
     """A fresh (or reset) buffer holds nothing: len 0, empty views and returns (buffer.rs:123-129,
     187-225 with len = 0), an empty pass (data.rs:117), NaN explained variance (0/0)."""
