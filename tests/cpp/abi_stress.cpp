@@ -194,6 +194,17 @@ int main() {
   REQUIRE(ppo_xp_set_exchange(h, 1, nullptr) == PPO_XP_EINVAL);
   REQUIRE(ppo_xp_attach_comm(h, nullptr, 0, 1) == 0);                        // detaches: mode 0
 
+  // ---- rows from page-locked host memory ------------------------------------------------------
+  {
+    float *pin = (float *)ppo_xp_host_alloc(N * D * sizeof(float));
+    REQUIRE(pin != nullptr);
+    for (size_t i = 0; i < N * D; ++i) pin[i] = r.obs[i];
+    REQUIRE(ppo_xp_add(h, pin, r.rewards.data(), r.actions.data(), r.values.data(), r.dones.data(), r.neglogps.data(), N) == 0);
+    ppo_xp_host_free(pin);
+    ppo_xp_host_free(nullptr);
+    REQUIRE(ppo_xp_pass_begin(h, 8, nullptr, 1) == PPO_XP_ESTATE);           // an insert invalidates the returns
+  }
+
   // ---- the second handle lives through all of the above ----------------------------------------
   Rollout r2(3, 3, 7, 2);
   REQUIRE(ppo_xp_add_many(h2, r2.obs.data(), r2.rewards.data(), r2.actions.data(), r2.values.data(), r2.dones.data(),
