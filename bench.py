@@ -2,13 +2,19 @@
 """bench.py — transitions/sec through GAE + advantage standardisation + one shuffled pass of K
 minibatch gathers (BASELINE.json's metric), on N GPUs of one node, env-sharded (weak scaling).
 
-  python bench.py [--gpus N --steps K --warmup W]          (N = 1)
+  python bench.py [--gpus N --steps K --warmup W]
+      N = 1: this process measures.  N > 1 without a torch.distributed environment: this process
+      starts the N ranks itself (python -m torch.distributed.run ... bench.py ...) BEFORE it touches
+      the GPU, passes rank 0's JSON line through and exits with the launcher's status.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+      one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).
 
 A step = ExperienceBuffer.returns(last_dones) [GAE kernel] followed by one full shuffled pass
 [gather + statistics + standardise kernels] over a synthetic rollout that is already resident in
 HBM.  Rollout insertion and permutation generation are outside the figure; they
-are timed separately and printed to stderr.  Rank 0 prints ONE JSON line on stdout.
+are timed separately and reported under "off_metric".  Rank 0 prints ONE JSON line on stdout: the
+headline is TGT (per GPU: weak scaling); "also" holds the other BASELINE.json configs measured the
+same way (one GPU: C2, C3, C4, C5 whole; N GPUs: C5 split over the ranks, strong scaling).
 """
 from __future__ import annotations
 
@@ -16,6 +22,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,180 +51,183 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(T, D, K, target_seconds=12.0):
-    """Times the CPU oracle (op-for-op restatement of the reference, single thread like the
-    reference) on a bounded sample of the same workload: same T, D, K, fewer envs."""
+# ---------------------------------------------------------------------------------------------
+# N > 1 started as a plain `python bench.py --gpus N`: become the launcher (no torch, no HIP here)
+# ---------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(n, argv, port):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n, argv) -> int:
+    """Starts the N ranks and relays rank 0's JSON line.  Runs before `import torch` / any HIP call
+    in this process: the children initialise the GPUs, the parent never does."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "8")
+    env["PPO_XP_SPAWNED"] = "1"
+    cmd = launcher_command(n, argv, _free_port())
+    log("bench.py: starting", n, "ranks:", " ".join(cmd))
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:                                   # the contract is ONE JSON line on stdout
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    if rc == 0 and line is None:
+        log("bench.py: the ranks exited cleanly but printed no result line")
+        return 1
+    return rc
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(T, N, D, K, target_seconds=10.0):
+    """Times the CPU oracle (op-for-op restatement of the reference) on the WHOLE workload (same T, N,
+    D, K): one thread like the reference, then every core this process may use."""
     from oracle import oracle as O
     from ppo_amd import synth
-    Ns = 16384
-    M = T * Ns
+    M = T * N
     B = M // K
-    r = synth.rollout(T, Ns, D, 0x5EED)
+    r = synth.rollout(T, N, D, 0x5EED)
     streams = dict(obs=r["obs"].reshape(M, D), rewards=r["rewards"].reshape(-1), actions=r["actions"].reshape(-1),
                    values=r["values"].reshape(-1), neglogps=r["neglogps"].reshape(-1),
                    dones=r["dones"].astype(np.float32).reshape(-1))
     perm = O.shuffle(0x5EED, M)
-    outs = O.run_pass(streams, T, Ns, D, T - 1, r["last_dones"], 0.99, 0.95, perm, B, nthreads=1)
+    outs = O.run_pass(streams, T, N, D, T - 1, r["last_dones"], 0.99, 0.95, perm, B, nthreads=1)
     times, t_end = [], time.time() + target_seconds
-    while time.time() < t_end or len(times) < 3:
+    while (time.time() < t_end and len(times) < 20) or len(times) < 3:
         t0 = time.perf_counter()
-        O.run_pass(streams, T, Ns, D, T - 1, r["last_dones"], 0.99, 0.95, perm, B, nthreads=1, outs=outs)
+        O.run_pass(streams, T, N, D, T - 1, r["last_dones"], 0.99, 0.95, perm, B, nthreads=1, outs=outs)
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    ncores = min(O.max_threads(), 16)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    nproc = os.cpu_count() or 1
+    env_cap = int(os.environ.get("OMP_NUM_THREADS", "0") or 0)
+    ncores = max(1, min(usable, O.max_threads()) if not env_cap else min(usable, env_cap, O.max_threads()))
     tm = []
     for _ in range(3):
         t0 = time.perf_counter()
-        O.run_pass(streams, T, Ns, D, T - 1, r["last_dones"], 0.99, 0.95, perm, B, nthreads=ncores, outs=outs)
+        O.run_pass(streams, T, N, D, T - 1, r["last_dones"], 0.99, 0.95, perm, B, nthreads=ncores, outs=outs)
         tm.append(time.perf_counter() - t0)
     return {"value": M / med, "unit": "transitions/s", "cores": 1, "kind": "port",
-            "sample": f"T={T}, N={Ns} envs (of the workload's per-GPU envs), obs_dim={D}, K={K} minibatches of {B}; "
-                      f"{len(times)} passes of the CPU oracle (oracle/ppo_xp_oracle.c, -O2 -ffp-contract=off), median; "
-                      "the Rust reference itself cannot be built here, the oracle is an upper bound on its speed",
-            "all_cores": {"value": M / min(tm), "cores": ncores}}
+            "sample": f"the whole workload: T={T}, N={N} envs, obs_dim={D}, K={K} minibatches of {B}; "
+                      f"{len(times)} passes of the CPU oracle (oracle/ppo_xp_oracle.c, -O2 -ffp-contract=off), median "
+                      f"{med:.3f} s per pass; the Rust reference itself cannot be built here, the oracle is an upper bound on its speed",
+            "cpu_model": _cpu_model(), "nproc": nproc, "usable_cores": usable,
+            "all_cores": {"value": M / min(tm), "cores": ncores,
+                          "note": "OpenMP over envs / rows; threads = the cores this process may use (OMP_NUM_THREADS cap honoured)"}}
 
 
-def quick_measure(cfg, device, steps=200, warmup=20):
-    """Untimed-by-events whole-step rate of another BASELINE.json config on one GPU (same step as the main
-    measurement: returns() + one shuffled pass, inputs resident), reported beside the headline."""
-    import torch
-    import ppo_amd
-    from ppo_amd import _lib, synth
-    T, N, D, B = synth.CONFIGS[cfg]
-    M, K = T * N, (T * N) // B
-    buf = ppo_amd.ExperienceBuffer(N, D, T, device=device)
-    buf.use_torch_stream()
-    L, h = _lib.load(), buf.handle
-    r = synth.rollout_device(T, N, D, synth.SEEDS[cfg], torch.device("cuda", device))
-    for t in range(T):
-        buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t], r["neglogps"][t])
-    last_dones = r["last_dones"].cpu().numpy()
-    ld_p = last_dones.ctypes.data_as(C.c_void_p)
-    _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
-    _lib.check(L.ppo_xp_pass_begin(h, B, None, synth.SEEDS[cfg]))
-    perm = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, device, buf).clone()
-    bv = _lib.BatchView()
-
-    def step():
-        _lib.check(L.ppo_xp_returns(h, ld_p, N, 0, None))
-        _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
-        n = 0
-        while L.ppo_xp_pass_next(h, C.byref(bv)) == 0:
-            n += 1
-        assert n == K
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    buf.close()
-    value = M * steps / dt
-    return {"workload": f"{cfg}: T={T}, N={N} envs, obs_dim={D}, batch={B} (K={K})", "value": value, "unit": "transitions/s",
-            "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
-            "hbm_roofline_frac_whole_step": value * alg_bytes_total(D) / (HBM_PEAK_GBS * 1e9)}
+# ---------------------------------------------------------------------------------------------
+# one configuration on this rank's GPU
+# ---------------------------------------------------------------------------------------------
+class Ctx:
+    def __init__(self, args, rank, world, local_rank, dev, multi):
+        self.args, self.rank, self.world, self.local_rank, self.dev, self.multi = args, rank, world, local_rank, dev, multi
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="TGT",
-                    help="TGT | C2 | C3: every rank owns the config's N envs; C5: its 1 048 576 envs and batch are split "
-                         "over the ranks; C4: GAE only (T=16384, N=1024)")
-    ap.add_argument("--gae", default=None, choices=["seq", "assoc"], help="GAE algorithm (default: seq; assoc for C4)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the C2 line that a default one-GPU run reports beside TGT")
-    ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
-    ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
-                    help="gloo = rehearsal of the multi-rank control flow with all ranks on one GPU")
-    ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
-    args = ap.parse_args()
-
-    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line
-    # there.  Everything below writes to stderr's file until the result is printed.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-
+def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tunables=()):
+    """returns() + one shuffled pass per step on config `cfg`; every rank owns the config's envs (C5: its
+    share).  Returns (result dict, M, D, K, gae_only) — the dict is complete on rank 0."""
     import torch
     import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}")
-    if args.backend == "gloo":
-        local_rank %= max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # PPO_XP_FORCE_PG=1: run the multi-rank control flow (process group, exchange, barriers) with ONE
-    # rank, the only RCCL rehearsal a one-GPU box allows
-    multi = world > 1 or os.environ.get("PPO_XP_FORCE_PG") == "1"
-    if multi:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-
     import ppo_amd
     from ppo_amd import _lib, sharded, synth
 
-    T, N, D, B = synth.CONFIGS[args.config]   # per-GPU shard: weak scaling, every rank owns N envs
-    if args.config == "C5":                   # SURVEY.md 8(d): N/G envs and B/G rows per GPU
+    args, rank, world, dev = ctx.args, ctx.rank, ctx.world, ctx.dev
+    T, N, D, B = synth.CONFIGS[cfg]           # per-GPU shard: weak scaling, every rank owns N envs
+    if cfg == "C5":                           # SURVEY.md 8(d): N/G envs and B/G rows per GPU
         assert N % world == 0 and B % world == 0
         N, B = N // world, B // world
     gae_only = B == 0
     M = T * N
     K = 0 if gae_only else M // B
-    algo = {"seq": 0, "assoc": 1}[args.gae or ("assoc" if args.config == "C4" else "seq")]
+    algo = {"seq": 0, "assoc": 1}[gae or ("assoc" if cfg == "C4" else "seq")]
     if gae_only:
         algo |= 0x100                         # PPO_XP_GAE_NO_PACK: no pass follows, no records needed
-    seed = synth.SEEDS[args.config] + 1000 * rank
+    seed = synth.SEEDS[cfg] + 1000 * rank
 
-    buf = ppo_amd.ExperienceBuffer(N, D, T, device=local_rank)
-    buf.use_torch_stream()                      # torch events / RCCL see the kernels' stream
-    for t in args.tunable:
+    buf = ppo_amd.ExperienceBuffer(N, D, T, device=ctx.local_rank)
+    buf.use_torch_stream()                    # torch events / RCCL see the kernels' stream
+    for t in tunables:
         k, v = t.split("=")
         buf.set_tunable(k, int(v))
     L, h = _lib.load(), buf.handle
 
     # ---- synthetic rollout, drawn on the device and inserted row by row (not timed) ----------
     t0 = time.perf_counter()
-    r = synth.rollout_device(T, N, D, seed, dev)
-    for t in range(T):
-        buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t],
-                                  r["neglogps"][t])
-    buf.sync()
+    if T * N * D * 4 > (8 << 30):             # draw large rollouts in slabs of time steps (bounded temporaries)
+        tstep = max(1, (4 << 30) // (N * D * 4))
+        last_dones = None
+        for tb in range(0, T, tstep):
+            r = synth.rollout_device(min(tstep, T - tb), N, D, seed + tb, dev)
+            for t in range(r["rewards"].shape[0]):
+                buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t],
+                                          r["neglogps"][t])
+            last_dones = r["last_dones"].cpu().numpy()
+            buf.sync()
+            del r
+    else:
+        r = synth.rollout_device(T, N, D, seed, dev)
+        for t in range(T):
+            buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t],
+                                      r["neglogps"][t])
+        last_dones = r["last_dones"].cpu().numpy()
+        buf.sync()
+        del r
     t_insert = time.perf_counter() - t0
-    last_dones = r["last_dones"].cpu().numpy()
-    del r
     torch.cuda.empty_cache()
 
-    # ---- permutations (host Fisher-Yates in the library, seeded; not timed) ------------------
-    t0 = time.perf_counter()
+    # ---- permutations: host Fisher-Yates in the library, seeded (reference-faithful; not timed), or the
+    # device generator for the very large passes where the host shuffle takes seconds ------------------
     ld_p = last_dones.ctypes.data_as(C.c_void_p)
     _lib.check(L.ppo_xp_returns(h, ld_p, N, algo, None))
-    perms = []
-    for i in range(0 if gae_only else 2):
-        _lib.check(L.ppo_xp_pass_begin(h, B, None, seed + i))
-        p = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, local_rank, buf)
-        buf.sync()
-        perms.append(p.clone())
-    t_perm = (time.perf_counter() - t0) / 2
-    exch = multi and not gae_only     # the exchange of minibatch sums only exists when there is a pass
+    perms, t_perm, perm_kind = [], 0.0, "none"
+    if not gae_only:
+        host_fy = M <= (1 << 25)
+        perm_kind = "host Fisher-Yates (rand 0.8.5 / ChaCha12)" if host_fy else "device generator (SplitMix64 keys + radix sort)"
+        t0 = time.perf_counter()
+        for i in range(2):
+            if host_fy:
+                _lib.check(L.ppo_xp_pass_begin(h, B, None, seed + i))
+            else:
+                _lib.check(L.ppo_xp_pass_begin_device_shuffle(h, B, seed + i))
+            p = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, ctx.local_rank, buf)
+            buf.sync()
+            perms.append(p.clone())
+        t_perm = (time.perf_counter() - t0) / 2
+    exch = ctx.multi and not gae_only     # the exchange of minibatch sums only exists when there is a pass
 
     # ---- exchange of the per-minibatch sums across ranks (the only cross-GPU step) -----------
-    comm = None
+    comm, sb = None, None
     if exch:
         if args.exchange == "rccl":
             uid = torch.zeros(128, dtype=torch.uint8)
@@ -233,14 +244,15 @@ def main():
         else:
             sb = sharded.ShardedBatcher(buf, B * world)      # global batch = world x local batch; sets exchange mode 2
 
+    bv = _lib.BatchView()
+
     def step(i):
         _lib.check(L.ppo_xp_returns(h, ld_p, N, algo, None))
         if gae_only:
             return
         _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perms[i & 1].data_ptr())))
-        if exch and args.exchange == "torch":
+        if sb is not None:
             sb.exchange()                                    # ONE all-reduce of 3K doubles, then standardise
-        bv = _lib.BatchView()
         n = 0
         while L.ppo_xp_pass_next(h, C.byref(bv)) == 0:
             n += 1
@@ -248,68 +260,159 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if multi:
+        if ctx.multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     barrier()
     # timed region: HIP events only around the dominant kernel (an event pair costs ~7 us of stream time)
     dom = "gae_scan" if gae_only else "gather"      # the dominant kernel of the step
-    buf.prof_enable(False if args.no_kernel_events else [dom])
+    buf.prof_enable([dom] if events else False)
     buf.prof_collect()
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
     prof = buf.prof_collect()
-    # per-kernel breakdown: a few more steps with every kernel bracketed, outside the timed region
-    buf.prof_enable(True)
-    for i in range(5):
-        step(i)
-    barrier()
-    prof_all = buf.prof_collect()
+    prof_all = {}
+    if breakdown:   # per-kernel breakdown: a few more steps with every kernel bracketed, outside the timed region
+        buf.prof_enable(True)
+        for i in range(5):
+            step(i)
+        barrier()
+        prof_all = buf.prof_collect()
     buf.prof_enable(False)
 
-    if multi:
+    extra = {}
+    if cfg == "C4" and rank == 0:
+        # the looser bound of the associative scan, measured here: K2 against K1 on this very rollout
+        r1 = buf.returns(last_dones, algo=0).clone()
+        r2 = buf.returns(last_dones, algo=1)
+        err = ((r2 - r1).abs() / r1.abs().clamp(min=1.0)).max().item()
+        extra["assoc_vs_sequential_max_rel_err"] = err
+        extra["assoc_bound_stated"] = 1e-5
+        del r1, r2
+
+    if ctx.multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    if comm is not None:
+        buf.sync()
+        L.ppo_xp_rccl_comm_destroy(comm)
+    buf.close()
+    del perms
+    torch.cuda.empty_cache()
+
+    ms_per_step = dt / steps * 1e3
+    value = world * M * steps / dt
+    g_ms, g_n = prof[dom]
+    g_avg_s = g_ms / max(g_n, 1) * 1e-3
+    dom_bytes = 20 if gae_only else alg_bytes_obs_gather(D)     # per transition, SURVEY.md 8(d)
+    step_bytes = 20 if gae_only else alg_bytes_total(D)
+    achieved = M * dom_bytes / g_avg_s / 1e9 if g_n else 0.0
+    kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
+    scan = "associative (chunked)" if algo & 1 else "sequential"
+    workload = (f"{cfg}: T={T}, N={N} envs per GPU, GAE + returns only, {scan} scan, gamma=0.99 lambda=0.95" if gae_only else
+                f"{cfg}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
+                f"gamma=0.99 lambda=0.95, {scan} GAE scan + one shuffled pass")
+    res = {
+        "value": value, "unit": "transitions/s", "ms_per_step": ms_per_step, "steps": steps, "warmup": warmup,
+        "scaling": "strong" if cfg == "C5" else "weak",
+        "config": {"workload": workload, "global_envs": world * N,
+                   "parallelism": f"env-sharded x{world}" if ctx.multi else "single GPU",
+                   "exchange": ((args.exchange + "/" + args.backend) if ctx.multi else "none")},
+        "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
+        "alg_bytes_per_transition": step_bytes,
+        "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "obs_gather_kernel", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "alg_bytes_per_launch": M * dom_bytes, "avg_launch_us": g_avg_s * 1e6, "launches_timed": g_n},
+        "kernels_untimed_breakdown": kern,
+        "off_metric": {"insert_s": t_insert, "perm_s": t_perm, "perm_kind": perm_kind},
+    }
+    res.update(extra)
+    return res, (T, N, D, K, gae_only)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="TGT",
+                    help="TGT | C2 | C3: every rank owns the config's N envs; C5: its 1 048 576 envs and batch are split "
+                         "over the ranks; C4: GAE only (T=16384, N=1024)")
+    ap.add_argument("--gae", default=None, choices=["seq", "assoc"], help="GAE algorithm (default: seq; assoc for C4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other configs that a default run reports under 'also'")
+    ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
+    ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
+                    help="gloo = rehearsal of the multi-rank control flow with all ranks on one GPU")
+    ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    # `python bench.py --gpus N` with no torch.distributed environment: start the N ranks from here,
+    # before this process imports torch or makes any HIP call.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    # RCCL prints a version banner on stdout at communicator creation; the contract is ONE JSON line
+    # there.  Everything below writes to stderr's file until the result is printed.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}: the process group decides (n_gpus = {world})")
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local_rank %= max(ndev, 1)
+    elif local_rank >= ndev:
+        log(f"bench.py: rank {rank} needs GPU {local_rank} but this node shows {ndev}; use --backend gloo to rehearse on fewer GPUs")
+        sys.exit(3)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    # PPO_XP_FORCE_PG=1: run the multi-rank control flow (process group, exchange, barriers) with ONE
+    # rank, the only RCCL rehearsal a one-GPU box allows
+    multi = world > 1 or os.environ.get("PPO_XP_FORCE_PG") == "1"
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        world = dist.get_world_size()          # n_gpus in the result line = the ranks the process group really has
+        rank = dist.get_rank()
+
+    ctx = Ctx(args, rank, world, local_rank, dev, multi)
+    res, (T, N, D, K, gae_only) = measure(ctx, args.config, args.steps, args.warmup, gae=args.gae,
+                                          events=not args.no_kernel_events, tunables=args.tunable)
+
+    out = None
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = world * M * args.steps / dt
-        g_ms, g_n = prof[dom]
-        g_avg_s = g_ms / max(g_n, 1) * 1e-3
-        dom_bytes = 20 if gae_only else alg_bytes_obs_gather(D)     # per transition, SURVEY.md 8(d)
-        step_bytes = 20 if gae_only else alg_bytes_total(D)
-        achieved = M * dom_bytes / g_avg_s / 1e9 if g_n else 0.0
-        kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
-            metric = "transitions/sec through GAE+norm+minibatch gather; % of HBM roofline, 1\u20138 GPU"
-        out = {
-            "metric": metric, "value": value, "unit": "transitions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong" if args.config == "C5" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"{args.config}: T={T}, N={N} envs per GPU, GAE + returns only, "
-                                    f"{'associative (chunked)' if algo & 1 else 'sequential'} scan, gamma=0.99 lambda=0.95") if gae_only else
-                                   (f"{args.config}: T={T}, N={N} envs per GPU, obs_dim={D}, batch={B} (K={K} minibatches/pass), "
-                                    f"gamma=0.99 lambda=0.95, {'associative' if algo & 1 else 'sequential'} GAE scan + one shuffled pass"),
-                       "global_envs": world * N, "parallelism": f"env-sharded x{world}" if multi else "single GPU",
-                       "exchange": ((args.exchange + "/" + args.backend) if multi else "none")},
-            "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
-            "alg_bytes_per_transition": step_bytes,
-            "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "obs_gather_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "alg_bytes_per_launch": M * dom_bytes, "avg_launch_us": g_avg_s * 1e6,
-                         "launches_timed": g_n},
-            "kernels_untimed_breakdown": kern,
-            "off_metric": {"insert_s": t_insert, "perm_host_fisher_yates_s": t_perm},
-        }
+            metric = "transitions/sec through GAE+norm+minibatch gather; % of HBM roofline, 1–8 GPU"
+        out = {"metric": metric, "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+               "scaling": res.pop("scaling"), "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        res.pop("steps"); res.pop("warmup")
+        out.update(res)
         traffic_file = os.path.join(ROOT, "profiles", "gather_traffic.json")
         if os.path.exists(traffic_file):
             try:
@@ -319,21 +422,35 @@ def main():
                     out["roofline"]["traffic_source"] = tf.get("source")
             except Exception:
                 pass
-        if not args.no_cpu_baseline and world == 1 and not gae_only:
-            out["cpu_baseline"] = cpu_baseline(T, D, K)
-    if comm is not None:
-        buf.sync()
-        L.ppo_xp_rccl_comm_destroy(comm)
-    buf.close()
-    if rank == 0:
-        # BASELINE.json's configs[1] (C2) beside the headline, measured the same way (no events at all)
-        if world == 1 and not multi and args.config == "TGT" and not args.no_secondary:
-            torch.cuda.empty_cache()
-            out["also"] = {"C2": quick_measure("C2", local_rank)}
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    # ---- the other BASELINE.json configs beside the headline, measured the same way ---------------
+    if args.config == "TGT" and not args.no_secondary:
+        also = {}
+        # one GPU: configs[1] C2, configs[2] C3, configs[3] C4 (GAE only, K2 + its error against K1) and C5 whole on
+        # this GPU (= the per-GPU shard of a 1-rank job); N GPUs: C5 split over the ranks (strong scaling)
+        todo = [("C5", 10, 3)] if world > 1 else [("C2", 200, 20), ("C4", 100, 10), ("C3", 12, 3), ("C5", 10, 3)]
+        for cfg, st, wu in todo:
+            try:
+                r2, _ = measure(ctx, cfg, st, wu, events=False, breakdown=(cfg != "C2"))
+                r2.pop("roofline", None)
+                also[cfg] = r2
+            except Exception as e:
+                if world > 1:           # a rank that gives up alone would leave the others inside a collective
+                    raise
+                # one GPU: a secondary line must never cost the headline
+                log(f"bench.py: secondary config {cfg} failed: {type(e).__name__}: {e}")
+                also[cfg] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+        if out is not None:
+            out["also"] = also
+
     if multi:
         dist.destroy_process_group()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not gae_only:
+            out["cpu_baseline"] = cpu_baseline(T, N, D, K)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

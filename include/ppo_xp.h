@@ -85,6 +85,23 @@ typedef struct ppo_batch_view {
   float adv_std;
 } ppo_batch_view;
 
+/* One minibatch in CALLER host memory: the six Vecs that the reference's next() hands to
+ * Tensor::copy_from (data.rs:166-182).  The caller sets the six pointers (each with room for
+ * `capacity` rows; page-locked memory from ppo_xp_host_alloc makes the copies DMA transfers) and
+ * `capacity`; ppo_xp_pass_next_host fills index / batch_size / obs_size and the arrays. */
+typedef struct ppo_batch_host {
+  size_t capacity;          /* in: rows each destination array can hold (>= batch_size)    */
+  size_t index;             /* out: k                                                      */
+  size_t batch_size;        /* out: B                                                      */
+  size_t obs_size;          /* out: D                                                      */
+  float *observations;      /* in: [capacity, D] host                                      */
+  size_t *actions;          /* in: [capacity] host, usize like the reference (data.rs:7)   */
+  float *values;            /* in: [capacity] host                                         */
+  float *neglogps;          /* in: [capacity] host                                         */
+  float *returns;           /* in: [capacity] host                                         */
+  float *advantages;        /* in: [capacity] host; standardised (data.rs:157-164)         */
+} ppo_batch_host;
+
 /* ---- lifetime -------------------------------------------------------------------------- */
 
 /* ExperienceBuffer::new_with_params (buffer.rs:52-69); `new` (buffer.rs:45-47) is gamma=0.99,
@@ -108,7 +125,11 @@ int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const siz
                     const float *vals, const uint8_t *dones, const float *neglogps, size_t n,
                     size_t steps);
 /* add_experience with DEVICE source rows (device-resident simulators / policies);
- * dones_f32 already 0.0/1.0.  Enqueued on the handle's stream. */
+ * dones_f32 already 0.0/1.0.  The six copies are ENQUEUED on the handle's stream and the call
+ * returns without waiting: the source arrays must stay valid and unchanged until that stream has
+ * passed them (ppo_xp_sync(), or an event recorded on ppo_xp_stream() after the call), and whatever
+ * produced them must be ordered before the call (same stream, or synchronised).  The Python mirror
+ * orders both ways against torch's current stream (ppo_amd/buffer.py add_experience_device). */
 int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions,
                       const float *vals, const float *dones_f32, const float *neglogps, size_t n);
 
@@ -145,7 +166,10 @@ int ppo_xp_explained_variance(ppo_xp *h, float *out);
 int ppo_xp_explained_variance_sums(ppo_xp *h, double *sums5);
 int ppo_xp_explained_variance_from_sums(const double *sums5, float *out);
 
-/* ExperienceBuffer::training_views (buffer.rs:142-175) + the batcher's master set. */
+/* ExperienceBuffer::training_views (buffer.rs:142-175) + the batcher's master set.  A pass reads the
+ * GAE results from packed records, so ppo_xp_returns(host_out = NULL) does not store the flat returns /
+ * advantages arrays; the first call here after such a ppo_xp_returns enqueues the small kernel that
+ * unpacks them on the handle's stream (same bits: ret as stored, adv' = fl(ret - v), data.rs:62). */
 int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out);
 
 /* ---- one shuffled pass over the buffer (IntoIterator + Iterator, data.rs:85-193) ------- */
@@ -173,6 +197,17 @@ int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed
 /* Iterator::next (data.rs:115-192): 0 = *out filled, 1 = exhausted (`None`), < 0 error.
  * The windows follow data.rs:121-126 exactly, including the overlapping tail batch. */
 int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out);
+/* Iterator::next (data.rs:115-192) as the reference's caller sees it: the six arrays of minibatch k in
+ * HOST memory (what data.rs:166-182 feeds to copy_from), so a Rust shim can keep returning
+ * ExperienceBatch<OBS_SIZE, D> on whatever device its learner uses.  Copies on the handle's stream
+ * and synchronises.  Same return values as ppo_xp_pass_next; io->capacity < B => PPO_XP_EINVAL and
+ * the minibatch is not consumed. */
+int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io);
+/* Starts drawing the host Fisher-Yates permutation for `seed` (and the current len) on a worker
+ * thread; a later ppo_xp_pass_begin(h, B, NULL, seed) with the same seed and M takes it instead of
+ * shuffling on the caller's thread (the reference draws a fresh permutation per pass, training.rs:204-205:
+ * prefetch pass i+1's while pass i trains).  Any other pass_begin simply discards it. */
+int ppo_xp_shuffle_prefetch(ppo_xp *h, uint64_t seed);
 /* Number of minibatches of the current pass (ExperienceBatcher::len()/B rounded up). */
 size_t ppo_xp_pass_num_batches(const ppo_xp *h);
 /* The permutation of the current pass on the device (u32[M]) / copied to the host. */
@@ -250,7 +285,8 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * documented tolerance of PPO_XP_GAE_ASSOC): "gather_nt" 0/1, "gather_block" 64/256, "gather_xcd" 0/1/2, "fold_tiles" 0..65536 (single-GPU passes with at most this many 256-row tiles per
  * minibatch skip the finalize launch: the standardise workgroups add the tile sums themselves),
  * "gae_waves" 0 (auto)/1/2/4/8/16 (waves per 64 envs of the sequential scan), "gae_unroll" 0 (auto)/4/8/16,
- * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams).
+ * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams),
+ * "gae_flat" 0/1 (1: the packing scan always stores the flat returns / advantages arrays too).
  * Unknown names or values => PPO_XP_EINVAL. */
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
 

@@ -33,6 +33,15 @@ inline int check(int rc) {
 // data.rs:4-12 — device pointers of one minibatch
 using ExperienceBatch = ppo_batch_view;
 
+// data.rs:4-12 with the arrays in host memory: what the reference's next() hands to copy_from (data.rs:166-182)
+template <size_t OBS_SIZE>
+struct HostExperienceBatch {
+  size_t index = 0;
+  std::vector<std::array<float, OBS_SIZE>> observations;
+  std::vector<size_t> actions;
+  std::vector<float> values, neglogps, returns, advantages;
+};
+
 template <size_t NUM_ENVS, size_t OBS_SIZE>
 class ExperienceBuffer {
  public:
@@ -92,6 +101,19 @@ class ExperienceBatcher {
       int rc = check(ppo_xp_pass_next(h_, &cur_));
       return rc == 0 ? &cur_ : nullptr;
     }
+    // the same minibatch in host vectors (ppo_xp_pass_next_host); false == None
+    bool next_host(HostExperienceBatch<OBS_SIZE> &b) {
+      b.observations.resize(batch_size_); b.actions.resize(batch_size_); b.values.resize(batch_size_);
+      b.neglogps.resize(batch_size_); b.returns.resize(batch_size_); b.advantages.resize(batch_size_);
+      ppo_batch_host io{};
+      io.capacity = batch_size_;
+      io.observations = batch_size_ ? b.observations[0].data() : nullptr; io.actions = b.actions.data();
+      io.values = b.values.data(); io.neglogps = b.neglogps.data(); io.returns = b.returns.data();
+      io.advantages = b.advantages.data();
+      if (check(ppo_xp_pass_next_host(h_, &io)) != 0) return false;
+      b.index = io.index;
+      return true;
+    }
     std::vector<uint32_t> perm() const {
       ppo_xp_views_t v; check(ppo_xp_views(h_, &v));
       std::vector<uint32_t> p(v.num_steps);
@@ -100,14 +122,28 @@ class ExperienceBatcher {
     }
    private:
     friend class ExperienceBatcher;
-    explicit Iter(ppo_xp *h) : h_(h) {}
+    Iter(ppo_xp *h, size_t batch_size) : h_(h), batch_size_(batch_size) {}
     ppo_xp *h_;
+    size_t batch_size_;
     ExperienceBatch cur_{};
   };
 
   // data.rs:91-102: a fresh (seeded) permutation per pass
-  Iter into_iter(uint64_t seed) { check(ppo_xp_pass_begin(buf_.handle(), batch_size_, nullptr, seed)); return Iter(buf_.handle()); }
-  Iter into_iter(const std::vector<uint32_t> &perm) { check(ppo_xp_pass_begin(buf_.handle(), batch_size_, perm.data(), 0)); return Iter(buf_.handle()); }
+  Iter into_iter(uint64_t seed) { check(ppo_xp_pass_begin(buf_.handle(), batch_size_, nullptr, seed)); return Iter(buf_.handle(), batch_size_); }
+  // a caller-supplied permutation: the ABI reads exactly len() entries, so a vector of another length is a
+  // panic here (the reference's indices vector always has buf_size entries, data.rs:93)
+  Iter into_iter(const std::vector<uint32_t> &perm) {
+    if (perm.size() != len()) throw Panic(PPO_XP_EINVAL, "into_iter: the permutation must have len() entries");
+    check(ppo_xp_pass_begin(buf_.handle(), batch_size_, perm.data(), 0));
+    return Iter(buf_.handle(), batch_size_);
+  }
+  // the permutation drawn on the device (no host Fisher-Yates on the critical path)
+  Iter into_iter_device_shuffle(uint64_t seed) {
+    check(ppo_xp_pass_begin_device_shuffle(buf_.handle(), batch_size_, seed));
+    return Iter(buf_.handle(), batch_size_);
+  }
+  // start drawing the Fisher-Yates of a coming into_iter(seed) on a worker thread
+  void prefetch_shuffle(uint64_t seed) { check(ppo_xp_shuffle_prefetch(buf_.handle(), seed)); }
 
  private:
   ExperienceBuffer<NUM_ENVS, OBS_SIZE> &buf_;

@@ -6,8 +6,8 @@ classes here mirror ppo/src/common/buffer.rs and ppo/src/model/data.rs.  There i
 """
 from ._lib import GAE_ASSOC, GAE_NO_PACK, GAE_SEQUENTIAL, PpoXpError, PpoXpPanic, gae_chunk
 from .buffer import ExperienceBuffer, device_tensor, pinned_empty
-from .data import ExperienceBatch, ExperienceBatcher, ExperienceBatcherIterator
+from .data import ExperienceBatch, ExperienceBatcher, ExperienceBatcherIterator, HostBatch
 from .runner import RewardNormalizer
 
-__all__ = ["ExperienceBuffer", "ExperienceBatch", "ExperienceBatcher", "ExperienceBatcherIterator", "RewardNormalizer", "PpoXpError",
+__all__ = ["ExperienceBuffer", "ExperienceBatch", "ExperienceBatcher", "ExperienceBatcherIterator", "HostBatch", "RewardNormalizer", "PpoXpError",
            "PpoXpPanic", "GAE_SEQUENTIAL", "GAE_ASSOC", "GAE_NO_PACK", "gae_chunk", "device_tensor", "pinned_empty"]

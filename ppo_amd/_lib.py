@@ -49,6 +49,12 @@ class BatchView(C.Structure):
                 ("adv_mean", C.c_float), ("adv_std", C.c_float)]
 
 
+class BatchHost(C.Structure):
+    _fields_ = [("capacity", C.c_size_t), ("index", C.c_size_t), ("batch_size", C.c_size_t), ("obs_size", C.c_size_t),
+                ("observations", C.c_void_p), ("actions", C.c_void_p), ("values", C.c_void_p),
+                ("neglogps", C.c_void_p), ("returns", C.c_void_p), ("advantages", C.c_void_p)]
+
+
 # name -> (restype, argtypes); every symbol include/ppo_xp.h declares.
 _vp, _sz, _i, _f, _u64 = C.c_void_p, C.c_size_t, C.c_int, C.c_float, C.c_uint64
 SYMBOLS = {
@@ -70,6 +76,8 @@ SYMBOLS = {
     "ppo_xp_explained_variance_sums": (_i, [_vp, C.POINTER(C.c_double)]),
     "ppo_xp_explained_variance_from_sums": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "ppo_xp_pass_next": (_i, [_vp, C.POINTER(BatchView)]),
+    "ppo_xp_pass_next_host": (_i, [_vp, C.POINTER(BatchHost)]),
+    "ppo_xp_shuffle_prefetch": (_i, [_vp, _u64]),
     "ppo_xp_pass_num_batches": (_sz, [_vp]),
     "ppo_xp_pass_perm_device": (_vp, [_vp]),
     "ppo_xp_pass_perm_host": (_i, [_vp, _vp, _sz]),

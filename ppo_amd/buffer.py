@@ -108,8 +108,10 @@ class ExperienceBuffer:
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
-            self._L.ppo_xp_destroy(self._h)
+            self._L.ppo_xp_destroy(self._h)       # synchronises the handle's stream first
             self._h = C.c_void_p()
+            self._pass_perm = None                # a borrowed permutation is no longer read by anything
+            self._ext_stream = None
 
     def __del__(self):
         try:
@@ -161,8 +163,29 @@ class ExperienceBuffer:
                 raise PpoXpPanic(_lib.EINVAL, "add_experience_device: contiguous CUDA tensors of f32/f32/i64/f32/f32/f32 expected")
         if obs.shape != (self.num_envs, self.obs_size) or any(t.shape != (self.num_envs,) for t in ts[1:]):
             raise PpoXpPanic(_lib.EINVAL, "add_experience_device: length != NUM_ENVS (reference panics, buffer.rs:97-112)")
-        torch.cuda.current_stream(self.device).synchronize()  # producers ran on torch's stream
+        # the six copies are only ENQUEUED on the handle's stream: order them after the producers (torch's
+        # current stream) and order torch's stream after them, so that neither an in-place update of the
+        # source tensors by the next simulator step nor the caching allocator recycling a temporary can
+        # race with a pending copy (no host synchronisation either way)
+        cur, hs = self._order_streams()
+        if hs is not None:
+            hs.wait_stream(cur)
         check(self._L.ppo_xp_add_device(self._h, *(C.c_void_p(t.data_ptr()) for t in ts), self.num_envs))
+        if hs is not None:
+            cur.wait_stream(hs)
+
+    def _order_streams(self):
+        """(torch's current stream, the handle's stream as a torch ExternalStream) — the second is None
+        when the handle already enqueues on torch's current stream (use_torch_stream())."""
+        import torch
+        cur = torch.cuda.current_stream(self.device)
+        ptr = self.stream_ptr or 0
+        if ptr == cur.cuda_stream:
+            return cur, None
+        ext = getattr(self, "_ext_stream", None)
+        if ext is None or ext.cuda_stream != ptr:
+            ext = self._ext_stream = torch.cuda.ExternalStream(ptr, device=torch.device("cuda", self.device))
+        return cur, ext
 
     def reset_counter(self):
         """buffer.rs:131-133."""
@@ -210,8 +233,9 @@ class ExperienceBuffer:
         if to_host:
             return host
         import torch
+        v = self._views()      # may enqueue the kernel that unpacks the flat arrays from the records
         self.sync()
-        return device_tensor(self._views().returns, (M,), torch.float32, self.device, self)
+        return device_tensor(v.returns, (M,), torch.float32, self.device, self)
 
     def explained_variance(self) -> float:
         """explained_variance(values, returns) of train() (training.rs:88-99), after returns()."""

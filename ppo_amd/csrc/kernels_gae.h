@@ -48,6 +48,9 @@ struct GaeArgs {
   unsigned N, len, lvi, chunk;                       // chunk = time steps per blockIdx.y
   float gamma, gl;                                   // gl = fl(gamma*lambda)  (buffer.rs:219)
   int nt;                                            // non-temporal inputs / returns / adv (records keep the default policy)
+  int flat;                                          // store the flat returns / adv arrays (always when no records are built);
+                                                     // a pass reads only the records, so the packing scan skips these 8 B per
+                                                     // transition unless a caller asked for the arrays (ppo_xp_views & co.)
 };
 
 // One time step of buffer.rs:217-222, in the reference's rounding order.
@@ -130,8 +133,10 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
         gae_step(rc[u], vc[u], v_next, nnt_next, a.gamma, a.gl, A, ret, adv);
         if (!SUMMARY) {
           size_t i = (size_t)t * N + e;
-          if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
-          else { a.returns[i] = ret; a.adv[i] = adv; }
+          if (!PACK || a.flat) {                 // kernel-uniform
+            if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
+            else { a.returns[i] = ret; a.adv[i] = adv; }
+          }
           if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
         }
         v_next = vc[u];
@@ -238,8 +243,10 @@ __global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
             const float ret = delta[u] + vc[u];          // buffer.rs:222
             const float adv = ret - vc[u];               // data.rs:62
             const size_t i = (size_t)t * N + e;
-            if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
-            else { a.returns[i] = ret; a.adv[i] = adv; }
+            if (!PACK || a.flat) {               // kernel-uniform
+              if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
+              else { a.returns[i] = ret; a.adv[i] = adv; }
+            }
             if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
           }
         }
@@ -314,6 +321,20 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float *__restri
                                                            Rec *__restrict__ rec, size_t M) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
     store_rec(rec + i, values[i], neglogps[i], returns[i], actions[i]);
+  }
+}
+
+// The flat returns / adv' arrays from the records, for callers that ask for them after a packing
+// scan that skipped them (ppo_xp_views, ppo_xp_returns with a host buffer): ret is stored in the
+// record as it was computed, adv' = fl(ret - v) is the very operation of data.rs:62.
+__global__ __launch_bounds__(256) void unpack_flat_kernel(const Rec *__restrict__ rec, float *__restrict__ returns,
+                                                          float *__restrict__ adv, size_t M) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
+    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(rec + i);
+    const float v = __uint_as_float(q.x), ret = __uint_as_float(q.z);
+    returns[i] = ret;
+    adv[i] = ret - v;
   }
 }
 

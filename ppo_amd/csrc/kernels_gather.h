@@ -192,7 +192,7 @@ __device__ __forceinline__ void stats_from_sums(const double *s, float &mean, fl
   const double n = s[0];
   const double m = s[1] / n;
   double var = (s[2] - s[1] * m) / n;                         // population variance (dfdx var)
-  var = var > 0.0 ? var : 0.0;
+  var = var < 0.0 ? 0.0 : var;                                // cancellation only; a NaN (inf / NaN advantages) stays NaN as in the reference
   mean = (float)m;
   const float nf = (float)n;
   const float corrected = (float)var * (nf / (nf - 1.0f));    // n == 1: 0 * inf = NaN, as the reference
@@ -240,12 +240,21 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_
 // explained_variance (ppo/src/training.rs:88-99) needs var(returns) and var(returns - values), both
 // with ddof 0.  One pass: fp64 (sum, sum of squares) of both streams per block -> partials[block]
 // = (S_ret, Q_ret, S_adv, Q_adv); the host adds the few thousand partials in block order.
+// rec != nullptr: the flat arrays were not written by the scan; ret and adv' = fl(ret - v) come from the records.
 __global__ __launch_bounds__(256) void moments_kernel(const float *__restrict__ ret, const float *__restrict__ adv,
-                                                      size_t M, double *__restrict__ partials) {
+                                                      const Rec *__restrict__ rec, size_t M,
+                                                      double *__restrict__ partials) {
   __shared__ double red[4][4];
   double s[4] = {0.0, 0.0, 0.0, 0.0};
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < M; i += (size_t)gridDim.x * 256u) {
-    const double r = ret[i], a = adv[i];
+    double r, a;
+    if (rec) {                                                  // kernel-uniform
+      const u32x4 q = *(reinterpret_cast<const u32x4 *>(rec) + i);
+      const float rf = __uint_as_float(q.z);
+      r = rf; a = rf - __uint_as_float(q.x);                    // data.rs:62 in fp32, then widened
+    } else {
+      r = ret[i]; a = adv[i];
+    }
     s[0] += r; s[1] += r * r; s[2] += a; s[3] += a * a;
   }
   const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "kernels_gae.h"
@@ -107,6 +108,7 @@ struct ppo_xp {
   float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
   size_t scan_cap = 0;       // elements allocated in carry/sumP/sumQ
   bool have_returns = false, have_rec = false;
+  bool have_flat = false;    // the flat returns / adv arrays hold the current GAE results (else only the records do)
   size_t ret_len = 0;        // len at the time of returns()
   // pass state — data.rs:105-109
   uint32_t *perm = nullptr;  // [capacity*N] owned copy (host-drawn permutations)
@@ -119,6 +121,8 @@ struct ppo_xp {
   size_t pass_B = 0, pass_K = 0, pass_M = 0, pass_iter = 0;
   bool pass_active = false, pass_pending_finish = false;
   std::vector<uint32_t> perm_host;
+  // Fisher-Yates of a coming pass drawn by a background thread (ppo_xp_shuffle_prefetch)
+  std::thread pf_thread; std::vector<uint32_t> pf_perm; uint64_t pf_seed = 0; size_t pf_M = 0; bool pf_valid = false;
   void *shuffle_ws = nullptr; size_t shuffle_ws_bytes = 0;   // device permutation generator workspace
   double *moments = nullptr;                                  // [kMomentBlocks][4] partials of explained_variance
   // exchange
@@ -129,7 +133,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0;
 };
 
 namespace {
@@ -223,7 +227,7 @@ int launch_gae_wide(ppo_xp *h, const GaeArgs &a, unsigned W) {
   return launch_check("gae_wide_kernel");
 }
 
-int run_gae(ppo_xp *h, int algo) {
+int run_gae(ppo_xp *h, int algo, bool want_flat) {
   const size_t len = buf_len(h);
   const size_t N = h->N;
   if (len == 0 || N == 0) return 0;
@@ -234,6 +238,7 @@ int run_gae(ppo_xp *h, int algo) {
   a.actions = h->actions; a.last_dones = h->last_dones_dev; a.returns = h->returns; a.adv = h->adv;
   a.rec = h->rec; a.N = (unsigned)N; a.len = (unsigned)len; a.lvi = (unsigned)h->last_values_idx;
   a.gamma = h->gamma; a.nt = (int)h->gae_nt;
+  a.flat = (!pack || want_flat || h->gae_flat) ? 1 : 0;
   a.gl = h->gamma * h->lambda;  // one fp32 product, computed first (buffer.rs:219)
   unsigned chunks = 1;
   a.chunk = (unsigned)len;
@@ -290,7 +295,23 @@ int run_gae(ppo_xp *h, int algo) {
   if (rc) return rc;
   h->have_returns = true;
   h->have_rec = pack;
+  h->have_flat = a.flat != 0;
   h->ret_len = len;
+  return 0;
+}
+
+// returns / adv as flat arrays, for the callers that read them (views, host copies): a packing scan
+// leaves them only inside the records.
+int ensure_flat(ppo_xp *h) {
+  if (!h->have_returns || h->have_flat) return 0;
+  const size_t M = h->ret_len * h->N;
+  if (M) {
+    HIP_TRY(hipSetDevice(h->device));
+    const unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, 1u << 20);
+    hipLaunchKernelGGL(unpack_flat_kernel, dim3(blocks), dim3(256), 0, h->stream, h->rec, h->returns, h->adv, M);
+    if (int rc = launch_check("unpack_flat_kernel")) return rc;
+  }
+  h->have_flat = true;
   return 0;
 }
 
@@ -336,8 +357,13 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
 }
 
 int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
-  const size_t rows = K * B;
+  // sized for this batch size at FULL capacity, so that a pass over a partly filled ring followed by
+  // one over the full ring does not move the slabs (views of the earlier pass stay valid memory);
+  // a larger batch size later still re-allocates: views die with the next pass_begin (include/ppo_xp.h)
+  const size_t Mcap = h->capacity * h->N;
+  const size_t rows = std::max(K * B, B <= Mcap ? ((Mcap + B - 1) / B) * B : (size_t)0);
   if (rows > h->slab_rows) {
+    HIP_TRY(hipStreamSynchronize(h->stream));   // kernels of the previous pass may still write the old slabs
     dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out);
     dev_free(h->ret_out); dev_free(h->adv_out); h->slab_rows = 0;
     if (int rc = dev_alloc(&h->obs_out, rows * h->D, false)) return rc;
@@ -348,7 +374,7 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
     if (int rc = dev_alloc(&h->adv_out, rows, false)) return rc;
     h->slab_rows = rows;
   }
-  const size_t tiles = K * ((B + 255) / 256);
+  const size_t tiles = std::max(K, B <= Mcap ? (Mcap + B - 1) / B : (size_t)0) * ((B + 255) / 256);
   if (tiles > h->partials_cap) {
     dev_free(h->partials); h->partials_cap = 0;
     if (int rc = dev_alloc(&h->partials, tiles, false)) return rc;
@@ -509,6 +535,7 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
 
 void ppo_xp_destroy(ppo_xp *h) {
   if (!h) return;
+  if (h->pf_thread.joinable()) h->pf_thread.join();
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -530,7 +557,7 @@ static void advance_counter(ppo_xp *h, size_t idx) {
   h->last_values_idx = idx;                                     // buffer.rs:115
   h->counter += 1;                                              // buffer.rs:117
   if (h->counter >= h->capacity) h->counter = (h->counter % h->capacity) + h->capacity;  // buffer.rs:118-120
-  h->have_returns = false; h->have_rec = false; h->pass_active = false;
+  h->have_returns = false; h->have_rec = false; h->have_flat = false; h->pass_active = false;
 }
 
 int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions, const float *vals,
@@ -601,7 +628,7 @@ void ppo_xp_host_free(void *p) { if (p) (void)hipHostFree(p); }
 
 void ppo_xp_reset_counter(ppo_xp *h) {                          // buffer.rs:131-133
   if (!h) return;
-  h->counter = 0; h->have_returns = false; h->have_rec = false; h->pass_active = false;
+  h->counter = 0; h->have_returns = false; h->have_rec = false; h->have_flat = false; h->pass_active = false;
 }
 size_t ppo_xp_len(const ppo_xp *h) { return h ? buf_len(h) : 0; }
 size_t ppo_xp_counter(const ppo_xp *h) { return h ? h->counter : 0; }
@@ -625,9 +652,9 @@ int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, flo
   HIP_TRY(hipEventRecord(h->pin_ev[slot], h->stream));
   h->pin_used[slot] = true;
   h->pass_active = false;
-  if (int rc = run_gae(h, algo)) return rc;
+  if (int rc = run_gae(h, algo, host_out != nullptr)) return rc;
   h->have_returns = true; h->ret_len = buf_len(h);
-  if (buf_len(h) == 0) h->have_rec = true;
+  if (buf_len(h) == 0) { h->have_rec = true; h->have_flat = true; }
   if (host_out) {
     const size_t M = buf_len(h) * h->N;
     if (M) HIP_TRY(hipMemcpyAsync(host_out, h->returns, M * sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -638,6 +665,8 @@ int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, flo
 
 int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out) {
   if (!h || !out) return fail(PPO_XP_EINVAL, "views: NULL argument");
+  // the handle is opaque: handing out returns / advantages may first have to unpack them from the records
+  if (int rc = ensure_flat(const_cast<ppo_xp *>(h))) return rc;
   out->num_steps = buf_len(h) * h->N; out->obs_size = h->D;
   out->observations = h->obs; out->actions = h->actions; out->values = h->values; out->neglogps = h->neglogps;
   out->rewards = h->rewards; out->dones = h->dones; out->returns = h->returns; out->advantages = h->adv;
@@ -652,13 +681,20 @@ int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64
   if (M) {
     // previous upload may still be reading perm_host
     HIP_TRY(hipStreamSynchronize(h->stream));
-    h->perm_host.resize(M);
-    if (perm) {
-      for (size_t i = 0; i < M; ++i)
-        if (perm[i] >= M) return fail(PPO_XP_EINVAL, "pass_begin: perm[%zu] = %u is out of range (M = %zu)", i, perm[i], M);
-      std::memcpy(h->perm_host.data(), perm, M * sizeof(uint32_t));
+    if (h->pf_thread.joinable()) h->pf_thread.join();
+    const bool prefetched = !perm && h->pf_valid && h->pf_seed == seed && h->pf_M == M;
+    h->pf_valid = false;
+    if (prefetched) {
+      h->perm_host.swap(h->pf_perm);                             // drawn while the previous pass ran
     } else {
-      shuffle_indices(seed, h->perm_host.data(), M);             // data.rs:93-95
+      h->perm_host.resize(M);
+      if (perm) {
+        for (size_t i = 0; i < M; ++i)
+          if (perm[i] >= M) return fail(PPO_XP_EINVAL, "pass_begin: perm[%zu] = %u is out of range (M = %zu)", i, perm[i], M);
+        std::memcpy(h->perm_host.data(), perm, M * sizeof(uint32_t));
+      } else {
+        shuffle_indices(seed, h->perm_host.data(), M);           // data.rs:93-95
+      }
     }
     HIP_TRY(hipMemcpyAsync(h->perm, h->perm_host.data(), M * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
   }
@@ -705,7 +741,8 @@ int ppo_xp_explained_variance_sums(ppo_xp *h, double *sums5) {
   if (!h->moments) { if (int rc = dev_alloc(&h->moments, 4 * (size_t)kBlocks, true)) return rc; }
   for (int k = 0; k < 5; ++k) sums5[k] = 0.0;
   if (M == 0) return 0;
-  hipLaunchKernelGGL(moments_kernel, dim3(kBlocks), dim3(256), 0, h->stream, h->returns, h->adv, M, h->moments);
+  hipLaunchKernelGGL(moments_kernel, dim3(kBlocks), dim3(256), 0, h->stream, h->returns, h->adv,
+                     h->have_flat ? (const Rec *)nullptr : h->rec, M, h->moments);
   if (int rc = launch_check("moments_kernel")) return rc;
   std::vector<double> part(4 * (size_t)kBlocks);
   HIP_TRY(hipMemcpyAsync(part.data(), h->moments, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -759,6 +796,50 @@ int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out) {
   out->returns = h->ret_out + k * B;
   out->advantages = h->adv_out + k * B;
   out->adv_mean = 0.f; out->adv_std = 0.f;
+  return 0;
+}
+
+int ppo_xp_shuffle_prefetch(ppo_xp *h, uint64_t seed) {
+  if (!h) return fail(PPO_XP_EINVAL, "shuffle_prefetch: handle is NULL");
+  if (h->pf_thread.joinable()) h->pf_thread.join();
+  const size_t M = buf_len(h) * h->N;
+  h->pf_valid = false;
+  if (M == 0) return 0;
+  h->pf_seed = seed; h->pf_M = M;
+  try {
+    h->pf_perm.resize(M);
+    uint32_t *dst = h->pf_perm.data();
+    h->pf_thread = std::thread([dst, seed, M] { shuffle_indices(seed, dst, M); });   // data.rs:93-95, off the caller's thread
+  } catch (...) {
+    return fail(PPO_XP_ENOMEM, "shuffle_prefetch: could not start the worker thread");
+  }
+  h->pf_valid = true;
+  return 0;
+}
+
+int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io) {
+  if (!h || !io) return fail(PPO_XP_EINVAL, "pass_next_host: NULL argument");
+  if (!io->observations || !io->actions || !io->values || !io->neglogps || !io->returns || !io->advantages)
+    return fail(PPO_XP_EINVAL, "pass_next_host: the six destination arrays must be set by the caller");
+  ppo_batch_view v;
+  const int rc = ppo_xp_pass_next(h, &v);
+  if (rc != 0) return rc;
+  if (io->capacity < v.batch_size) {
+    h->pass_iter -= h->pass_B;                                   // nothing was consumed
+    return fail(PPO_XP_EINVAL, "pass_next_host: destination holds %zu rows, the minibatch has %zu", io->capacity, v.batch_size);
+  }
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t B = v.batch_size, D = v.obs_size;
+  io->index = v.index; io->batch_size = B; io->obs_size = D;
+  static_assert(sizeof(size_t) == sizeof(int64_t), "usize actions travel as 64-bit words");
+  // data.rs:166-182 uploads six host Vecs; here the six device arrays of minibatch k come down instead
+  HIP_TRY(hipMemcpyAsync(io->observations, v.observations, B * D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(io->actions, v.actions, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(io->values, v.values, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(io->neglogps, v.neglogps, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(io->returns, v.returns, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(io->advantages, v.advantages, B * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
 }
 
@@ -885,6 +966,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "gae_waves" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) h->gae_waves = value;
   else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
+  else if (n == "gae_flat" && (value == 0 || value == 1)) h->gae_flat = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16)) h->gae_unroll = value;

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void rnorm_apply_kernel(float *__restrict__ re
     if (global) { n = global[0]; t1 = global[1]; t2 = global[2]; }
     const double bm = t1 / n;
     double bv = (t2 - t1 * bm) / n;
-    bv = bv > 0.0 ? bv : 0.0;
+    bv = bv < 0.0 ? 0.0 : bv;                                          // cancellation only; NaN (inf or NaN returns) stays NaN like the reference's Welford
     // update_from_moments, running_mean_std.rs:45-67, fp32, operation order as written there
     const RmsState c = *cur;
     const float batch_mean = (float)bm, batch_var = (float)bv, b_count = (float)n;
@@ -112,7 +112,10 @@ __global__ __launch_bounds__(256) void rnorm_apply_kernel(float *__restrict__ re
   if (e < N) {
     const float denom = sqrtf(s_var + epsilon);                        // runner.rs:121
     float x = rews[e] / denom;
-    x = fminf(fmaxf(x, -cliprew), cliprew);                            // runner.rs:122 (f32::clamp)
+    // runner.rs:122 f32::clamp: two ordered comparisons, so a NaN reward stays NaN (fminf/fmaxf
+    // would turn it into -cliprew)
+    if (x < -cliprew) x = -cliprew;
+    if (x > cliprew) x = cliprew;
     out[e] = x;
     ret[e] = ret[e] * dones[e];                                        // runner.rs:124 (sic)
   }

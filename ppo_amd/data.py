@@ -34,6 +34,43 @@ class ExperienceBatch:
     advantages: "torch.Tensor"    # [batch_size], standardised per minibatch (data.rs:157-164)
 
 
+class HostBatch:
+    """Host-memory ExperienceBatch (ppo_batch_host): the six arrays data.rs:166-182 hands to copy_from."""
+
+    def __init__(self, arrays, capacity):
+        self.observations, self.actions, self.values, self.neglogps, self.returns, self.advantages = arrays
+        self.index = -1
+        self._c = _lib.BatchHost()
+        self._c.capacity = capacity
+        for name, a in zip(("observations", "actions", "values", "neglogps", "returns", "advantages"), arrays):
+            setattr(self._c, name, a.ctypes.data)
+
+    @classmethod
+    def pinned(cls, capacity, obs_size):
+        from .buffer import pinned_empty
+        f = np.float32
+        return cls([pinned_empty((capacity, obs_size), f), pinned_empty((capacity,), np.uint64), pinned_empty((capacity,), f),
+                    pinned_empty((capacity,), f), pinned_empty((capacity,), f), pinned_empty((capacity,), f)], capacity)
+
+    @classmethod
+    def pageable(cls, capacity, obs_size):
+        f = np.float32
+        return cls([np.empty((capacity, obs_size), f), np.empty((capacity,), np.uint64), np.empty((capacity,), f),
+                    np.empty((capacity,), f), np.empty((capacity,), f), np.empty((capacity,), f)], capacity)
+
+    def view(self, rows, index):
+        """The first `rows` rows (the arrays are sized for `capacity`)."""
+        self.index = index
+        if rows == self._c.capacity:
+            return self
+        b = HostBatch.__new__(HostBatch)
+        b._c, b.index = self._c, index
+        b.observations, b.actions, b.values = self.observations[:rows], self.actions[:rows], self.values[:rows]
+        b.neglogps, b.returns, b.advantages = self.neglogps[:rows], self.returns[:rows], self.advantages[:rows]
+        b._owner = self
+        return b
+
+
 class ExperienceBatcher:
     """data.rs:14-83.  Holds the buffer whose views it was built from and a batch size."""
 
@@ -66,6 +103,11 @@ class ExperienceBatcher:
     def __iter__(self):
         return self.into_iter()
 
+    def prefetch_shuffle(self, seed: int):
+        """Draw the host Fisher-Yates of a coming pass on a worker thread of the library; the
+        into_iter(seed=seed) that follows takes it (training.rs:204-205: one fresh permutation per pass)."""
+        check(self._L.ppo_xp_shuffle_prefetch(self.buffer.handle, int(seed) & 0xFFFFFFFFFFFFFFFF))
+
     def into_iter(self, seed: int | None = None, perm=None, device_shuffle: bool = False):
         """data.rs:91-102: a fresh permutation per pass.  perm: optional host u32 array or CUDA
         int32 tensor of M indices.  device_shuffle=True draws the permutation on the GPU (stable
@@ -81,11 +123,25 @@ class ExperienceBatcherIterator:
         buf, L = batcher.buffer, batcher._L
         h = buf.handle
         B = batcher.batch_size
+        if getattr(buf, "_pass_perm", None) is not None:
+            # the previous pass borrowed a torch tensor: order torch's stream behind the kernels that read
+            # it before the allocator may hand its memory to someone else
+            cur, hs = buf._order_streams()
+            if hs is not None:
+                cur.wait_stream(hs)
+            buf._pass_perm = None
         if perm is not None and hasattr(perm, "is_cuda") and perm.is_cuda:
             import torch
             if perm.numel() != len(batcher) or perm.dtype not in (torch.int32,) or not perm.is_contiguous():
                 raise PpoXpPanic(_lib.EINVAL, "perm: contiguous CUDA int32 tensor of M indices expected")
-            torch.cuda.current_stream(buf.device).synchronize()
+            # the library BORROWS the array until the pass's kernels have run: the buffer keeps it alive until
+            # its next pass (released there only after torch's stream has been ordered behind the handle's),
+            # or a temporary such as randperm(M).int() would go back to torch's allocator while the gathers
+            # are still pending on the handle's stream
+            buf._pass_perm = perm
+            cur, hs = buf._order_streams()
+            if hs is not None:
+                hs.wait_stream(cur)                 # whatever produced perm ran on torch's stream
             check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
         elif perm is not None:
             p = np.ascontiguousarray(perm, dtype=np.uint32)
@@ -120,6 +176,18 @@ class ExperienceBatcherIterator:
             device_tensor(v.observations, (B, D), f32, d, buf), device_tensor(v.actions, (B,), i64, d, buf),
             device_tensor(v.values, (B,), f32, d, buf), device_tensor(v.neglogps, (B,), f32, d, buf),
             device_tensor(v.returns, (B,), f32, d, buf), device_tensor(v.advantages, (B,), f32, d, buf))
+
+    def next_host(self, out: "HostBatch | None" = None) -> "HostBatch | None":
+        """Iterator::next as the reference's caller sees it (data.rs:166-182 feeds six host Vecs to
+        copy_from): minibatch k copied into host arrays (page-locked when `out` comes from
+        HostBatch.pinned).  Returns None when the pass is exhausted."""
+        buf = self.batcher.buffer
+        if out is None:
+            out = HostBatch.pinned(self.batcher.batch_size, buf.obs_size)
+        rc = check(self.batcher._L.ppo_xp_pass_next_host(buf.handle, C.byref(out._c)))
+        if rc == 1:
+            return None
+        return out.view(out._c.batch_size, out._c.index)
 
     def perm(self) -> np.ndarray:
         """The permutation of this pass (host copy)."""

@@ -72,9 +72,9 @@ class ShardedBatcher:
     """ExperienceBatcher for one rank of an env-sharded job.
 
     `group` is a torch.distributed process group (None = the default group).  With the nccl backend
-    the all-reduce runs on the sums in device memory on the buffer's stream (make the buffer use
-    torch's stream: buffer.use_torch_stream()); with gloo the 3K doubles take a round trip through
-    the host (tests)."""
+    the all-reduce runs on the sums in device memory on torch's current stream, ordered against the
+    buffer's stream by event waits (none needed after buffer.use_torch_stream()); with gloo the 3K
+    doubles take a round trip through the host (tests)."""
 
     def __init__(self, buffer: ExperienceBuffer, global_batch_size: int, group=None, seed: int = 0x5EED):
         import torch.distributed as dist
@@ -104,7 +104,15 @@ class ShardedBatcher:
         if K:
             sums = self.buffer.pass_sums(K)
             if self.dist.get_backend(self.group) == "nccl":
+                # RCCL orders the all-reduce against torch's CURRENT stream; the sums are written, and the
+                # standardise kernel launched, on the handle's stream.  When the two differ (no
+                # buffer.use_torch_stream()), bracket the collective with stream-to-stream waits.
+                cur, hs = self.buffer._order_streams()
+                if hs is not None:
+                    cur.wait_stream(hs)
                 self.dist.all_reduce(sums, group=self.group)
+                if hs is not None:
+                    hs.wait_stream(cur)
             else:
                 self.buffer.sync()
                 host = sums.cpu()

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <set>
 
 #include "ppo_xp.hpp"
@@ -106,6 +107,61 @@ static void batcher_sanity() {              // data.rs:210-270
   for (long v : {0, 1, 2, 3, 4, 100, 101, 102, 103, 104}) EXPECT(seen.count(v) == 1);
 }
 
+// The shim's next() keeps the reference's type: ExperienceBatch in host vectors (data.rs:166-182 hands
+// exactly these to copy_from).  Rows must be src[perm[j]] bit for bit; the standardised advantages must be
+// the bits the device minibatch holds.  Also: a permutation of the wrong length panics.
+static void batcher_host_batches() {
+  auto buf = ExperienceBuffer<2, 3>::make(10);
+  std::vector<float> obs0;
+  for (int i = 0; i < 5; ++i) {
+    buf.add_experience({{0.5f + i, 1, 2}, {100.25f + i, 2, 3}}, {0.1f * i, 1.1f}, {size_t(1 + i), size_t(1) << 40}, {3.0f + i, 6}, {0, 0}, {20, 21.5f + i});
+    for (float x : {0.5f + i, 1.f, 2.f, 100.25f + i, 2.f, 3.f}) obs0.push_back(x);
+  }
+  auto ret = buf.returns({0, 1});
+  ExperienceBatcher<2, 3> batcher(buf, 6);
+  bool threw = false;
+  try { batcher.into_iter(std::vector<uint32_t>{0, 1, 2}); } catch (const Panic &) { threw = true; }
+  EXPECT(threw);
+  // device batches of the pass with seed 7
+  std::vector<std::vector<float>> dev_adv, dev_val;
+  {
+    auto it = batcher.into_iter(7);
+    while (const ExperienceBatch *b = it.next()) {
+      ppo_xp_sync(buf.handle());
+      dev_adv.push_back(to_host(b->advantages, b->batch_size));
+      dev_val.push_back(to_host(b->values, b->batch_size));
+    }
+  }
+  batcher.prefetch_shuffle(7);                 // the same permutation, drawn by the worker thread
+  auto it = batcher.into_iter(7);
+  auto perm = it.perm();
+  EXPECT(perm.size() == 10);
+  HostExperienceBatch<3> hb;
+  size_t k = 0;
+  while (it.next_host(hb)) {
+    EXPECT(hb.index == k && hb.observations.size() == 6);
+    const size_t start = k == 0 ? 0 : 4;       // data.rs:121-125: the tail window is [M-B, M)
+    for (size_t j = 0; j < 6; ++j) {
+      const uint32_t p = perm[start + j];
+      for (int c = 0; c < 3; ++c) EXPECT(hb.observations[j][c] == obs0[3 * p + c]);
+      EXPECT(hb.returns[j] == ret[p]);
+      EXPECT(hb.actions[j] == ((p & 1) ? (size_t(1) << 40) : size_t(1 + p / 2)));
+      EXPECT(hb.values[j] == dev_val[k][j]);
+      EXPECT(std::memcmp(&hb.advantages[j], &dev_adv[k][j], 4) == 0);
+    }
+    ++k;
+  }
+  EXPECT(k == 2 && dev_adv.size() == 2);
+  // a destination that is too small is refused and the minibatch is not consumed
+  auto it2 = batcher.into_iter(8);
+  ppo_batch_host io{};
+  std::vector<float> f(6 * 3); std::vector<size_t> a(6);
+  io.capacity = 5; io.observations = f.data(); io.actions = a.data(); io.values = f.data(); io.neglogps = f.data();
+  io.returns = f.data(); io.advantages = f.data();
+  EXPECT(ppo_xp_pass_next_host(buf.handle(), &io) == PPO_XP_EINVAL);
+  EXPECT(it2.next() != nullptr && it2.next() != nullptr && it2.next() == nullptr);
+}
+
 int main() {
   try {
     exp_buffer_below_capacity();
@@ -113,6 +169,7 @@ int main() {
     exp_buffer_returns_sanity();
     panics();
     batcher_sanity();
+    batcher_host_batches();
   } catch (const std::exception &e) { std::printf("exception: %s\n", e.what()); return 2; }
   std::printf(failures ? "%d FAILURES\n" : "all reference cases passed (%d failures)\n", failures);
   return failures ? 1 : 0;

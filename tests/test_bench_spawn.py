@@ -1,0 +1,75 @@
+"""`python bench.py --gpus N` (the way the driver calls it) must start its own N ranks, from a parent
+that never touches the GPU, relay rank 0's single JSON line and fail when the launcher fails."""
+import io
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_launcher_command_is_torchrun_on_localhost():
+    b = _bench()
+    cmd = b.launcher_command(4, ["--gpus", "4", "--steps", "7"], 29511)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "7"] and cmd[-5].endswith("bench.py")
+
+
+class _FakePopen:
+    def __init__(self, lines, rc):
+        self.stdout, self.rc = io.StringIO("".join(lines)), rc
+
+    def wait(self):
+        return self.rc
+
+
+def test_spawn_relays_one_json_line_and_the_exit_status(monkeypatch, capsys):
+    b = _bench()
+    seen = {}
+    line = json.dumps({"metric": "m", "value": 1.0, "n_gpus": 2}) + "\n"
+
+    def fake(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return _FakePopen(["RCCL version banner\n", line, "trailing noise\n"], 0)
+    monkeypatch.setattr(b.subprocess, "Popen", fake)
+    assert b.spawn_ranks(2, ["--gpus", "2"]) == 0
+    out = capsys.readouterr()
+    assert out.out == line                       # exactly the one line; everything else went to stderr
+    assert "RCCL version banner" in out.err
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "--nproc-per-node=2" in seen["cmd"]
+    monkeypatch.setattr(b.subprocess, "Popen", lambda *a, **k: _FakePopen([line], 5))
+    assert b.spawn_ranks(2, []) == 5             # a failing rank fails the run
+    monkeypatch.setattr(b.subprocess, "Popen", lambda *a, **k: _FakePopen([], 0))
+    assert b.spawn_ranks(2, []) == 1             # no result line is a failure too
+
+
+def test_parent_spawns_before_importing_torch():
+    """The real thing on this CPU-only machine: the parent must reach the launcher without importing torch
+    (so without any HIP call), the two ranks start, find no GPU and fail, and the parent reports that."""
+    code = (
+        "import sys, runpy\n"
+        "sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0', '--backend', 'gloo', '--no-secondary']\n"
+        "import subprocess\n"
+        "real = subprocess.Popen\n"
+        "def spy(*a, **k):\n"
+        "    assert 'torch' not in sys.modules, 'parent imported torch before spawning'\n"
+        "    print('SPAWNED', a[0][1:4], file=sys.stderr)\n"
+        "    return real(*a, **k)\n"
+        "subprocess.Popen = spy\n"
+        "runpy.run_path(%r, run_name='__main__')\n" % os.path.join(ROOT, "bench.py"))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert "SPAWNED ['-m', 'torch.distributed.run', '--nnodes=1']" in p.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0 and p.stdout.strip() == ""

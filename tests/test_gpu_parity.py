@@ -443,6 +443,29 @@ def test_reward_normalizer(xp, oracle, N):
     g.close()
 
 
+def test_reward_normalizer_nan_and_inf_rewards(xp, oracle):
+    """runner.rs:122 is f32::clamp, which keeps NaN (two ordered comparisons) where fminf/fmaxf would
+    return the bound.  A NaN reward makes that env's discounted return, hence the batch moments and the
+    denominator, NaN: every normalised reward of the step is NaN in the reference, and stays NaN
+    afterwards.  +-inf rewards do the same through inf - inf.  The kernel must agree element by element."""
+    N = 130
+    rng = np.random.default_rng(5)
+    dones = np.zeros(N, bool)
+    for bad in (np.nan, np.inf, -np.inf):
+        g, o = xp.RewardNormalizer(N), oracle.OracleRewardNormalizer(N)
+        for step in range(4):
+            rews = rng.standard_normal(N).astype(np.float32)
+            if step == 1:
+                rews[7] = bad
+            a, b = g.normalized_rewards(rews, dones), o.normalized_rewards(rews, dones)
+            np.testing.assert_array_equal(np.isnan(a), np.isnan(b))
+            fin = ~np.isnan(b)
+            np.testing.assert_allclose(a[fin], b[fin], rtol=2e-5, atol=1e-6)
+            if step >= 1 and np.isnan(bad):
+                assert np.isnan(a).all()
+        g.close()
+
+
 def test_reward_normalizer_device_tensors(xp, oracle):
     import torch
     N = 1000
