@@ -156,6 +156,19 @@ size_t ppo_xp_last_values_idx(const ppo_xp *h);
  * returns to it (synchronises).  n != num_envs => PPO_XP_EINVAL (buffer.rs:194). */
 int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out);
 
+/* ppo_xp_returns for callers that cannot allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, results and bits as
+ * ppo_xp_returns; the difference is where the associative scan (PPO_XP_GAE_ASSOC) keeps its chunk maps and
+ * carries: ppo_xp_returns grows three device arrays on demand (hipMalloc), this entry point uses a
+ * file-scope __device__ array of 3 x 2^20 floats (12 MiB, held by every GPU the library runs on until the
+ * process ends) and calls no hipMalloc / hipFree / allocating routine; per-kernel profiling events are
+ * taken from the handle's pool only.  Limit: chunks x num_envs <= 2^20 (chunks = ceil(len / chunk
+ * length); choose longer chunks with PPO_XP_GAE_CHUNK) - beyond it the call fails with PPO_XP_EINVAL
+ * and does nothing.  Every call on one GPU shares that GPU's array: nothing in it has to start at zero
+ * (each call writes every entry it later reads), but calls that overlap on one GPU - two handles on two
+ * streams - race on it. */
+int ppo_xp_returns_noalloc(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out);
+
 /* explained_variance(values, returns) of train() (ppo/src/training.rs:88-99, called at :189):
  * 0 - var(returns - values) / var(returns), population variances (fp64 sums on the device; the
  * reference runs ndarray's sequential fp32 Welford).  Needs ppo_xp_returns() first; synchronises. */

@@ -68,6 +68,7 @@ SYMBOLS = {
     "ppo_xp_counter": (_sz, [_vp]),
     "ppo_xp_last_values_idx": (_sz, [_vp]),
     "ppo_xp_returns": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "ppo_xp_returns_noalloc": (_i, [_vp, _vp, _sz, _i, _vp]),
     "ppo_xp_views": (_i, [_vp, C.POINTER(ViewsT)]),
     "ppo_xp_pass_begin": (_i, [_vp, _sz, _vp, _u64]),
     "ppo_xp_pass_begin_device": (_i, [_vp, _sz, _vp]),

@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -86,6 +87,37 @@ constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclS
 }  // namespace
 
 // ---------------------------------------------------------------------------------------
+// Static scratch of ppo_xp_returns_noalloc: the chunk maps (P, Q) and the chunk carries of the
+// associative scan for callers that cannot allocate (HIP graph capture, serving loops).  One copy of
+// the array lives on every GPU the library runs on, for the life of the process (12 MiB each).
+// In host code the NAME `scratch` is only a stand-in for the symbol: the device address is asked
+// for once per device with hipGetSymbolAddress (that device current) and kept in g_scratch_ptr;
+// every kernel argument below is that pointer, never the name.
+// ---------------------------------------------------------------------------------------
+constexpr size_t kScratchPairs = size_t(1) << 20;           // (chunk, env) pairs one call may use
+static __device__ __align__(256) float scratch[3 * kScratchPairs];   // [0]: P  [1]: Q  [2]: carry
+namespace {
+constexpr int kMaxDevices = 64;
+float *g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
+
+// Call with `device` current.
+int scratch_for_device(int device, float **out) {
+  if (device < 0 || device >= kMaxDevices) return ppoxp_fail(PPO_XP_EINVAL, "device %d is beyond the %d devices the static scratch is tracked for", device, kMaxDevices);
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (!g_scratch_ptr[device]) {
+    float *ptr = nullptr;
+    hipError_t e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !ptr)
+      return ppoxp_fail(PPO_XP_EIO, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(e));
+    g_scratch_ptr[device] = ptr;
+  }
+  *out = g_scratch_ptr[device];
+  return 0;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------
 struct ProfRec { int kid; hipEvent_t a, b; };
@@ -130,6 +162,7 @@ struct ppo_xp {
   // stream / profiling
   hipStream_t stream = nullptr; bool own_stream = false;
   unsigned prof = 0;   // bit k set: record an event pair around every launch of kernel id k
+  bool no_alloc_call = false;   // inside ppo_xp_returns_noalloc: nothing may allocate, events included
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
@@ -154,6 +187,7 @@ struct ProfScope {
   }
   hipEvent_t take() {
     if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+    if (h->no_alloc_call) return nullptr;   // no pooled event left: this launch goes untimed
     hipEvent_t e = nullptr;
     if (hipEventCreate(&e) != hipSuccess) return nullptr;
     return e;
@@ -227,7 +261,9 @@ int launch_gae_wide(ppo_xp *h, const GaeArgs &a, unsigned W) {
   return launch_check("gae_wide_kernel");
 }
 
-int run_gae(ppo_xp *h, int algo, bool want_flat) {
+// static_scratch != nullptr: the chunk maps and carries of the associative scan live there (3 x kScratchPairs
+// floats) and nothing is allocated; else in the handle's own buffers, grown on demand.
+int run_gae(ppo_xp *h, int algo, bool want_flat, float *static_scratch = nullptr) {
   const size_t len = buf_len(h);
   const size_t N = h->N;
   if (len == 0 || N == 0) return 0;
@@ -260,7 +296,11 @@ int run_gae(ppo_xp *h, int algo, bool want_flat) {
   }
   if (chunks > 1) {
     const size_t need = (size_t)chunks * N;
-    if (need > h->scan_cap) {
+    if (static_scratch) {
+      if (need > kScratchPairs)
+        return fail(PPO_XP_EINVAL, "returns_noalloc: %u chunks x %zu envs = %zu chunk maps, the static scratch holds %zu "
+                    "(use fewer, longer chunks with PPO_XP_GAE_CHUNK, or ppo_xp_returns)", chunks, N, need, kScratchPairs);
+    } else if (need > h->scan_cap) {
       dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ); h->scan_cap = 0;
       if (int rc = dev_alloc(&h->carry, need, false)) return rc;
       if (int rc = dev_alloc(&h->sumP, need, false)) return rc;
@@ -268,6 +308,7 @@ int run_gae(ppo_xp *h, int algo, bool want_flat) {
       h->scan_cap = need;
     }
     a.carry = h->carry; a.sumP = h->sumP; a.sumQ = h->sumQ;
+    if (static_scratch) { a.sumP = static_scratch; a.sumQ = static_scratch + kScratchPairs; a.carry = static_scratch + 2 * kScratchPairs; }
     {
       dim3 grid((unsigned)((N + 63) / 64), chunks - 1), block(64);
       ProfScope ps(h, PPO_XP_K_GAE_SUMMARY);
@@ -280,11 +321,11 @@ int run_gae(ppo_xp *h, int algo, bool want_flat) {
       dim3 grid((unsigned)((N + 63) / 64));
       ProfScope ps(h, PPO_XP_K_GAE_CARRY);
       if (h->carry_waves == 4)
-        hipLaunchKernelGGL((gae_carry_scan_kernel<4>), grid, dim3(256), 0, h->stream, h->sumP, h->sumQ, h->carry, (unsigned)N, chunks);
+        hipLaunchKernelGGL((gae_carry_scan_kernel<4>), grid, dim3(256), 0, h->stream, a.sumP, a.sumQ, const_cast<float *>(a.carry), (unsigned)N, chunks);
       else if (h->carry_waves == 8)
-        hipLaunchKernelGGL((gae_carry_scan_kernel<8>), grid, dim3(512), 0, h->stream, h->sumP, h->sumQ, h->carry, (unsigned)N, chunks);
+        hipLaunchKernelGGL((gae_carry_scan_kernel<8>), grid, dim3(512), 0, h->stream, a.sumP, a.sumQ, const_cast<float *>(a.carry), (unsigned)N, chunks);
       else
-        hipLaunchKernelGGL((gae_carry_scan_kernel<16>), grid, dim3(1024), 0, h->stream, h->sumP, h->sumQ, h->carry, (unsigned)N, chunks);
+        hipLaunchKernelGGL((gae_carry_scan_kernel<16>), grid, dim3(1024), 0, h->stream, a.sumP, a.sumQ, const_cast<float *>(a.carry), (unsigned)N, chunks);
       if (int rc = launch_check("gae_carry_scan_kernel")) return rc;
     }
   }
@@ -528,6 +569,8 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
   for (int i = 0; i < 4 && !rc; ++i)
     if (hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(PPO_XP_EIO, "create: device sync failed");
+  // set-up of the allocation-free entry point: this device's address of the static scratch
+  if (!rc) { float *sp = nullptr; rc = scratch_for_device(device, &sp); }
   if (rc) { ppo_xp_destroy(h); return rc; }
   *out = h;
   return 0;
@@ -634,7 +677,24 @@ size_t ppo_xp_len(const ppo_xp *h) { return h ? buf_len(h) : 0; }
 size_t ppo_xp_counter(const ppo_xp *h) { return h ? h->counter : 0; }
 size_t ppo_xp_last_values_idx(const ppo_xp *h) { return h ? h->last_values_idx : 0; }
 
+static int returns_impl(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out, float *static_scratch);
+
 int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out) {
+  return returns_impl(h, last_dones, n, algo, host_out, nullptr);
+}
+
+int ppo_xp_returns_noalloc(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out) {
+  if (!h) return fail(PPO_XP_EINVAL, "returns: handle is NULL");
+  HIP_TRY(hipSetDevice(h->device));
+  float *sp = nullptr;
+  if (int rc = scratch_for_device(h->device, &sp)) return rc;   // looked up at create(); no allocation either way
+  h->no_alloc_call = true;
+  const int rc = returns_impl(h, last_dones, n, algo, host_out, sp);
+  h->no_alloc_call = false;
+  return rc;
+}
+
+static int returns_impl(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out, float *static_scratch) {
   if (!h) return fail(PPO_XP_EINVAL, "returns: handle is NULL");
   if (n != h->N)
     return fail(PPO_XP_EINVAL, "returns: last_dones has %zu entries, buffer has %zu envs (reference panics, buffer.rs:194)", n, h->N);
@@ -652,7 +712,7 @@ int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, flo
   HIP_TRY(hipEventRecord(h->pin_ev[slot], h->stream));
   h->pin_used[slot] = true;
   h->pass_active = false;
-  if (int rc = run_gae(h, algo, host_out != nullptr)) return rc;
+  if (int rc = run_gae(h, algo, host_out != nullptr, static_scratch)) return rc;
   h->have_returns = true; h->ret_len = buf_len(h);
   if (buf_len(h) == 0) { h->have_rec = true; h->have_flat = true; }
   if (host_out) {
