@@ -66,9 +66,9 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nblocks, unsi
 // V = floats per access (4 when D % 4 == 0, else 2 or 1), POW2 = Q is a power of two,
 // TAIL = the last window overlaps (B does not divide M), NT = non-temporal accesses.
 template <int V, int BS, bool NT, bool POW2, bool TAIL>
-__global__ __launch_bounds__(BS) void obs_gather_kernel(ObsGatherArgs g) {
+__device__ __forceinline__ void obs_gather_body(const ObsGatherArgs &g, size_t block) {
   using vec = typename VecT<V>::type;
-  const size_t e = (size_t)xcd_remap(blockIdx.x, g.nblocks, g.xcd) * BS + threadIdx.x;   // output vector element
+  const size_t e = block * BS + threadIdx.x;                  // output vector element
   if (e >= g.total) return;
   size_t row; unsigned col;                                   // output row (k*B + r), vector column
   if (POW2) { row = e >> g.qshift; col = (unsigned)e & (g.Q - 1); }
@@ -86,6 +86,11 @@ __global__ __launch_bounds__(BS) void obs_gather_kernel(ObsGatherArgs g) {
   else *d = *s;
 }
 
+template <int V, int BS, bool NT, bool POW2, bool TAIL>
+__global__ __launch_bounds__(BS) void obs_gather_kernel(ObsGatherArgs g) {
+  obs_gather_body<V, BS, NT, POW2, TAIL>(g, xcd_remap(blockIdx.x, g.nblocks, g.xcd));
+}
+
 struct ScalarGatherArgs {
   const Rec *rec;          // [M]
   const int64_t *actions;  // [M] (only read for actions that do not fit the record)
@@ -94,7 +99,7 @@ struct ScalarGatherArgs {
   float *val_out, *nlp_out, *ret_out, *adv_out;  // [K*B]; adv_out holds RAW adv' until normalize
   double2 *partials;       // [K * tiles_per_mb] (sum, sum of squares) per 256-row tile
   size_t M, B;
-  unsigned tiles_per_mb;   // ceil(B / 256)
+  unsigned tiles_per_mb;   // ceil(B / rows per tile); a tile = the rows of one workgroup = one (sum, sumsq) partial
   int rec_nt, out_nt;      // cache policy of the record reads / of the output stores
 };
 
@@ -104,16 +109,16 @@ __device__ __forceinline__ double wave_sum(double x) {
   return x;
 }
 
-// Scalar streams + advantage statistics.  grid = K * tiles_per_mb workgroups of 256 threads,
-// lane = one output row: one random 16-byte record read, five coalesced stores, and the
-// (sum, sum of squares) of the raw advantages of the tile in fp64.
-__global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) {
-  __shared__ double red[4][2];
-  const unsigned tile = blockIdx.x;
+// Scalar streams + advantage statistics of one tile of BS rows (BS = 256: scalar_gather_kernel, BS = 64: the
+// scalar workgroups of mixed_gather_kernel).  Lane = one output row: one random 16-byte record read, five
+// coalesced stores, and the (sum, sum of squares) of the tile's raw advantages in fp64.
+template <int BS>
+__device__ __forceinline__ void scalar_gather_body(const ScalarGatherArgs &g, unsigned tile) {
+  __shared__ double red[BS / 64][2];
   const unsigned k = tile / g.tiles_per_mb;
   const unsigned c = tile - k * g.tiles_per_mb;
   const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-  const size_t r = (size_t)c * 256u + threadIdx.x;            // row inside minibatch k
+  const size_t r = (size_t)c * BS + threadIdx.x;              // row inside minibatch k
   size_t start = (size_t)k * g.B;
   if (start + g.B > g.M) start = g.M - g.B;                   // data.rs:121-122
   const bool valid = r < g.B;
@@ -140,12 +145,114 @@ __global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) 
   }
   const double a = valid ? (double)adv : 0.0;
   const double s1 = wave_sum(a), s2 = wave_sum(a * a);
+  if (BS == 64) {
+    if (lane == 0) g.partials[tile] = make_double2(s1, s2);
+    return;
+  }
   if (lane == 0) { red[w][0] = s1; red[w][1] = s2; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
-    const double t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    double t1 = 0.0, t2 = 0.0;
+    if (BS == 256) {                                          // the tree of round 1: same bits
+      t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+      t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
+    } else {
+      for (int i = 0; i < BS / 64; ++i) { t1 += red[i][0]; t2 += red[i][1]; }
+    }
     g.partials[tile] = make_double2(t1, t2);
+  }
+}
+
+// grid = K * tiles_per_mb workgroups of 256 threads.
+__global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) { scalar_gather_body<256>(g, blockIdx.x); }
+
+// Observation rows AND scalar streams in ONE launch: a grid of 64-thread workgroups in which every
+// (ratio+1)-th workgroup is a scalar tile (64 rows, lane = row) and the others are observation workgroups
+// exactly as in obs_gather_kernel (thread = one 16-byte element).  Both keep the shape that is fastest for
+// them on their own; being in one grid, the record lines (random 128-B fetches, latency bound, served by
+// the Infinity Cache while the records fit) travel under the observation rows' HBM stream instead of after
+// it.  nbo observation workgroups, nbs scalar tiles; workgroup b is a scalar tile iff
+// floor((b+1)*nbs/total) != floor(b*nbs/total), which spreads them evenly (and over all XCDs).
+struct MixedGatherArgs {
+  ObsGatherArgs o;
+  ScalarGatherArgs s;
+  unsigned long long nbo, nbs;
+};
+
+template <int V, bool NT, bool POW2, bool TAIL>
+__global__ __launch_bounds__(64) void mixed_gather_kernel(MixedGatherArgs g) {
+  const unsigned long long b = blockIdx.x, total = g.nbo + g.nbs;
+  const unsigned long long before = (b * g.nbs) / total;      // scalar tiles among workgroups [0, b)
+  if (((b + 1) * g.nbs) / total != before) scalar_gather_body<64>(g.s, (unsigned)before);
+  else obs_gather_body<V, 64, NT, POW2, TAIL>(g.o, (size_t)(b - before));
+}
+
+// EXPERIMENT (tunable "fused" = 1, D % 4 == 0, Q = D/4 a power of two <= 16, B % RPW == 0): observation rows
+// AND the scalar streams of RPW = 256/Q output rows in one workgroup.  Thread = one 16-byte element of one
+// row, as in obs_gather_kernel; the first RPW lanes of wave 0 also fetch the rows' records and store the
+// five scalar streams (RPW*4 contiguous bytes per stream) and the tile's fp64 (sum, sum of squares).
+// Purpose: the record lines (served by the Infinity Cache when the records fit it) travel while the
+// observation rows stream from HBM, instead of in a kernel of their own.
+struct FusedGatherArgs {
+  ObsGatherArgs o;
+  ScalarGatherArgs s;
+  unsigned rpw;            // observation rows per workgroup = BS / Q
+  unsigned srows;          // scalar rows per workgroup (<= 64), a multiple of rpw: workgroup b gathers the scalar
+                           // streams of rows [b*srows, (b+1)*srows), so with srows = S*rpw the first 1/S of the grid
+                           // finishes them while the records are still in the Infinity Cache
+};
+
+template <int BS, bool NT, bool TAIL>
+__global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
+  const unsigned Q = g.o.Q, rpw = g.rpw;
+  const size_t row0 = (size_t)blockIdx.x * rpw;
+  const size_t KB = g.o.total >> g.o.qshift;                  // K*B output rows
+  // ---- observation element of this thread
+  {
+    const size_t row = row0 + (threadIdx.x >> g.o.qshift);
+    const unsigned col = threadIdx.x & (Q - 1);
+    if (row < KB) {
+      size_t pos = row;
+      if (TAIL) {
+        const size_t k = row / g.o.B, start = k * g.o.B;
+        if (start + g.o.B > g.o.M) pos = row - start + (g.o.M - g.o.B);
+      }
+      uint32_t p = g.o.perm[pos];
+      p = min(p, (uint32_t)(g.o.M - 1));
+      const f32x4 *s = reinterpret_cast<const f32x4 *>(g.o.obs) + ((size_t)p * Q + col);
+      f32x4 *d = reinterpret_cast<f32x4 *>(g.o.obs_out) + (row * Q + col);
+      if (NT) __builtin_nontemporal_store(__builtin_nontemporal_load(s), d);
+      else *d = *s;
+    }
+  }
+  // ---- scalar streams: the first srows lanes of wave 0
+  const size_t srow0 = (size_t)blockIdx.x * g.srows;
+  if (threadIdx.x < 64 && srow0 < KB) {
+    const size_t row = srow0 + threadIdx.x;
+    const bool valid = threadIdx.x < g.srows && row < KB;
+    float adv = 0.f;
+    if (valid) {
+      size_t pos = row;
+      if (TAIL) {
+        const size_t k = row / g.o.B, start = k * g.o.B;
+        if (start + g.o.B > g.o.M) pos = row - start + (g.o.M - g.o.B);
+      }
+      uint32_t p = g.s.perm[pos];
+      p = min(p, (uint32_t)(g.s.M - 1));
+      const u32x4 q = *(reinterpret_cast<const u32x4 *>(g.s.rec) + p);
+      const float v = __uint_as_float(q.x), nlp = __uint_as_float(q.y), ret = __uint_as_float(q.z);
+      int64_t act = (int64_t)q.w;
+      if (q.w == kRecActEscape) act = g.s.actions[p];
+      adv = ret - v;                                          // data.rs:62
+      __builtin_nontemporal_store(v, g.s.val_out + row);
+      __builtin_nontemporal_store(nlp, g.s.nlp_out + row);
+      __builtin_nontemporal_store(ret, g.s.ret_out + row);
+      __builtin_nontemporal_store(act, g.s.act_out + row);
+      g.s.adv_out[row] = adv;
+    }
+    const double a = valid ? (double)adv : 0.0;
+    const double s1 = wave_sum(a), s2 = wave_sum(a * a);
+    if (threadIdx.x == 0) g.s.partials[blockIdx.x] = make_double2(s1, s2);   // tile = srows rows (B % srows == 0)
   }
 }
 

@@ -166,7 +166,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = 0, fused_block = 256, mixed = 0, fused_dense = 1;
 };
 
 namespace {
@@ -397,7 +397,44 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
   return launch_check("obs_gather_kernel");
 }
 
-int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
+template <int V>
+void launch_mixed_v(ppo_xp *h, const MixedGatherArgs &m, unsigned blocks, bool pow2, bool tail) {
+  dim3 grid(blocks), block(64);
+  if (pow2) {
+    if (tail) hipLaunchKernelGGL((mixed_gather_kernel<V, true, true, true>), grid, block, 0, h->stream, m);
+    else hipLaunchKernelGGL((mixed_gather_kernel<V, true, true, false>), grid, block, 0, h->stream, m);
+  } else {
+    if (tail) hipLaunchKernelGGL((mixed_gather_kernel<V, true, false, true>), grid, block, 0, h->stream, m);
+    else hipLaunchKernelGGL((mixed_gather_kernel<V, true, false, false>), grid, block, 0, h->stream, m);
+  }
+}
+
+int launch_mixed_gather(ppo_xp *h, const ScalarGatherArgs &sg, size_t K, size_t B, size_t M) {
+  const unsigned D = (unsigned)h->D;
+  const int V = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
+  MixedGatherArgs m{};
+  ObsGatherArgs &g = m.o;
+  g.obs = h->obs; g.perm = h->perm_cur; g.obs_out = h->obs_out; g.M = M; g.B = B;
+  g.Q = D / V;
+  g.total = K * B * g.Q;
+  const bool pow2 = (g.Q & (g.Q - 1)) == 0;
+  g.qshift = 0;
+  if (pow2) while ((1u << g.qshift) < g.Q) ++g.qshift;
+  const bool tail = K * B != M;
+  m.s = sg;
+  m.nbo = (g.total + 63) / 64;
+  m.nbs = (unsigned long long)K * sg.tiles_per_mb;
+  const unsigned long long blocks = m.nbo + m.nbs;
+  if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch (%llu workgroups)", blocks);
+  g.nblocks = (unsigned)m.nbo; g.xcd = 0;
+  ProfScope ps(h, PPO_XP_K_GATHER);
+  if (V == 4) launch_mixed_v<4>(h, m, (unsigned)blocks, pow2, tail);
+  else if (V == 2) launch_mixed_v<2>(h, m, (unsigned)blocks, pow2, tail);
+  else launch_mixed_v<1>(h, m, (unsigned)blocks, pow2, tail);
+  return launch_check("mixed_gather_kernel");
+}
+
+int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   // sized for this batch size at FULL capacity, so that a pass over a partly filled ring followed by
   // one over the full ring does not move the slabs (views of the earlier pass stay valid memory);
   // a larger batch size later still re-allocates: views die with the next pass_begin (include/ppo_xp.h)
@@ -415,7 +452,7 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
     if (int rc = dev_alloc(&h->adv_out, rows, false)) return rc;
     h->slab_rows = rows;
   }
-  const size_t tiles = std::max(K, B <= Mcap ? (Mcap + B - 1) / B : (size_t)0) * ((B + 255) / 256);
+  const size_t tiles = std::max(K, B <= Mcap ? (Mcap + B - 1) / B : (size_t)0) * ((B + tile_rows - 1) / tile_rows);
   if (tiles > h->partials_cap) {
     dev_free(h->partials); h->partials_cap = 0;
     if (int rc = dev_alloc(&h->partials, tiles, false)) return rc;
@@ -431,12 +468,12 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B) {
 }
 
 // fold = true: no finalize_stats launch preceded; the normalize workgroups reduce the partials themselves.
-int pass_finish_impl(ppo_xp *h, bool fold = false) {
+int pass_finish_impl(ppo_xp *h, bool fold = false, unsigned fold_stat_tiles = 0) {
   const size_t K = h->pass_K, B = h->pass_B;
   if (K == 0) { h->pass_pending_finish = false; return 0; }
   const size_t nbx = (B + 1023) / 1024;
   if (K * nbx > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for the normalize launch");
-  const unsigned stat_tiles = (unsigned)((B + 255) / 256);
+  const unsigned stat_tiles = fold_stat_tiles ? fold_stat_tiles : (unsigned)((B + 255) / 256);
   ProfScope ps(h, PPO_XP_K_NORMALIZE);
   if (fold)
     hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)(K * nbx)), dim3(256), 0, h->stream, h->adv_out, h->sums,
@@ -458,7 +495,15 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   const size_t K = h->pass_K;
   if (K == 0) return 0;
   if (K * ((B + 255) / 256) > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
-  if (int rc = ensure_pass_buffers(h, K, B)) return rc;
+  // rows per statistics tile (= per workgroup of whichever kernel gathers the scalar streams)
+  const unsigned Dq = (unsigned)h->D / 4;
+  const unsigned FBq = (unsigned)h->fused_block;
+  const unsigned srows = Dq ? std::min(64u, (FBq / std::max(Dq, 1u)) * (unsigned)h->fused_dense) : 0u;
+  const bool fusable = h->fused && h->xmode == 0 && h->D % 4 == 0 && Dq >= 4 && Dq <= FBq && FBq / Dq <= 64 && (Dq & (Dq - 1)) == 0 &&
+                       srows && B % srows == 0;
+  const bool mixed = !fusable && h->mixed && K * ((B + 63) / 64) <= 0x3fffffffull;
+  const size_t tile_rows = fusable ? srows : mixed ? 64 : 256;
+  if (int rc = ensure_pass_buffers(h, K, B, tile_rows)) return rc;
   if (!h->have_rec) {
     ProfScope ps(h, PPO_XP_K_PACK);
     unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, 0x7fffffffull);
@@ -467,6 +512,46 @@ int pass_begin_body(ppo_xp *h, size_t B) {
     if (int rc = launch_check("pack_records_kernel")) return rc;
     h->have_rec = true;
   }
+  {
+    // EXPERIMENT: one kernel for rows and scalar streams (see fused_gather_kernel)
+    const unsigned Q = Dq;
+    const unsigned FB = FBq;
+    if (fusable) {
+      FusedGatherArgs f{};
+      f.rpw = FB / Q; f.srows = srows;
+      f.o.obs = h->obs; f.o.perm = h->perm_cur; f.o.obs_out = h->obs_out; f.o.M = M; f.o.B = B; f.o.Q = Q;
+      f.o.total = K * B * Q; f.o.qshift = 0;
+      while ((1u << f.o.qshift) < Q) ++f.o.qshift;
+      f.s.rec = h->rec; f.s.actions = h->actions; f.s.perm = h->perm_cur; f.s.act_out = h->act_out;
+      f.s.val_out = h->val_out; f.s.nlp_out = h->nlp_out; f.s.ret_out = h->ret_out; f.s.adv_out = h->adv_out;
+      f.s.partials = h->partials; f.s.M = M; f.s.B = B; f.s.tiles_per_mb = (unsigned)(B / srows);
+      const size_t blocks = K * (B / f.rpw);
+      if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
+      {
+        ProfScope ps(h, PPO_XP_K_GATHER);
+        const bool tail = K * B != M;
+        const dim3 grid((unsigned)blocks);
+        if (FB == 256) {
+          if (tail) hipLaunchKernelGGL((fused_gather_kernel<256, true, true>), grid, dim3(256), 0, h->stream, f);
+          else hipLaunchKernelGGL((fused_gather_kernel<256, true, false>), grid, dim3(256), 0, h->stream, f);
+        } else if (FB == 512) {
+          if (tail) hipLaunchKernelGGL((fused_gather_kernel<512, true, true>), grid, dim3(512), 0, h->stream, f);
+          else hipLaunchKernelGGL((fused_gather_kernel<512, true, false>), grid, dim3(512), 0, h->stream, f);
+        } else {
+          if (tail) hipLaunchKernelGGL((fused_gather_kernel<1024, true, true>), grid, dim3(1024), 0, h->stream, f);
+          else hipLaunchKernelGGL((fused_gather_kernel<1024, true, false>), grid, dim3(1024), 0, h->stream, f);
+        }
+        if (int rc = launch_check("fused_gather_kernel")) return rc;
+      }
+      {
+        ProfScope ps(h, PPO_XP_K_FINALIZE);
+        hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
+                           f.s.tiles_per_mb, B);
+        if (int rc = launch_check("finalize_stats_kernel")) return rc;
+      }
+      return pass_finish_impl(h, false);
+    }
+  }
   // scalar streams + statistics first (the records were just written by the GAE kernel and are
   // the most likely bytes to still sit in the Infinity Cache), observation rows after
   ScalarGatherArgs g{};
@@ -474,6 +559,23 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   g.val_out = h->val_out; g.nlp_out = h->nlp_out; g.ret_out = h->ret_out; g.adv_out = h->adv_out;
   g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256);
   g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
+  if (mixed) {
+    // rows and scalar streams in one grid of 64-thread workgroups (mixed_gather_kernel)
+    g.tiles_per_mb = (unsigned)((B + 63) / 64);
+    if (int rc = launch_mixed_gather(h, g, K, B, M)) return rc;
+    const bool fold = h->xmode == 0 && g.tiles_per_mb <= (unsigned)h->fold_tiles;
+    if (!fold) {
+      ProfScope ps(h, PPO_XP_K_FINALIZE);
+      hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
+                         g.tiles_per_mb, B);
+      if (int rc = launch_check("finalize_stats_kernel")) return rc;
+    }
+    if (h->xmode == 0) return pass_finish_impl(h, fold, g.tiles_per_mb);
+    if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
+    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+    return pass_finish_impl(h);
+  }
   {
     ProfScope ps(h, PPO_XP_K_SCALARS);
     hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
@@ -1027,6 +1129,10 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
   else if (n == "gae_flat" && (value == 0 || value == 1)) h->gae_flat = value;
+  else if (n == "fused" && (value == 0 || value == 1)) h->fused = value;
+  else if (n == "mixed" && (value == 0 || value == 1)) h->mixed = value;
+  else if (n == "fused_dense" && (value == 1 || value == 2 || value == 4 || value == 8)) h->fused_dense = value;
+  else if (n == "fused_block" && (value == 256 || value == 512 || value == 1024)) h->fused_block = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16)) h->gae_unroll = value;

@@ -22,6 +22,9 @@ def main():
     dev = torch.device("cuda", 0)
     buf = ppo_amd.ExperienceBuffer(N, D, T)
     buf.use_torch_stream()
+    for kv in filter(None, os.environ.get("PPO_XP_TUNABLES", "").split(",")):   # e.g. fused=1,gae_flat=1
+        k, v = kv.split("=")
+        buf.set_tunable(k, int(v))
     r = synth.rollout_device(T, N, D, 1, dev)
     for t in range(T):
         buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t], r["neglogps"][t])
