@@ -47,6 +47,10 @@ def alg_bytes_obs_gather(D):
     return 8 * D
 
 
+def alg_bytes_fused_gather(D):   # rows + the scalar gather's share: index I, actions 2A, v/nlp/ret 24, advantage read + raw write 8
+    return 8 * D + INDEX_BYTES + 2 * ACTION_BYTES + 24 + 8
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -267,6 +271,7 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     for i in range(warmup):
         step(i)
     barrier()
+    fused = (not gae_only) and L.ppo_xp_pass_gather_kind(h) == 1
     # timed region: HIP events only around the dominant kernel (an event pair costs ~7 us of stream time)
     dom = "gae_scan" if gae_only else "gather"      # the dominant kernel of the step
     buf.prof_enable([dom] if events else False)
@@ -312,7 +317,7 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     value = world * M * steps / dt
     g_ms, g_n = prof[dom]
     g_avg_s = g_ms / max(g_n, 1) * 1e-3
-    dom_bytes = 20 if gae_only else alg_bytes_obs_gather(D)     # per transition, SURVEY.md 8(d)
+    dom_bytes = 20 if gae_only else alg_bytes_fused_gather(D) if fused else alg_bytes_obs_gather(D)   # per transition, SURVEY.md 8(d)
     step_bytes = 20 if gae_only else alg_bytes_total(D)
     achieved = M * dom_bytes / g_avg_s / 1e9 if g_n else 0.0
     kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
@@ -328,7 +333,8 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
                    "exchange": ((args.exchange + "/" + args.backend) if ctx.multi else "none")},
         "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
         "alg_bytes_per_transition": step_bytes,
-        "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "obs_gather_kernel", "achieved": achieved,
+        "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "fused_gather_kernel" if fused else "obs_gather_kernel",
+                     "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes_per_launch": M * dom_bytes, "avg_launch_us": g_avg_s * 1e6, "launches_timed": g_n},
         "kernels_untimed_breakdown": kern,
@@ -417,7 +423,7 @@ def main():
         if os.path.exists(traffic_file):
             try:
                 tf = json.load(open(traffic_file))
-                if tf.get("config") == args.config and tf.get("kernel") == "obs_gather_kernel":
+                if tf.get("config") == args.config and tf.get("kernel") == out["roofline"]["kernel"]:
                     out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
                     out["roofline"]["traffic_source"] = tf.get("source")
             except Exception:
@@ -428,7 +434,7 @@ def main():
         also = {}
         # one GPU: configs[1] C2, configs[2] C3, configs[3] C4 (GAE only, K2 + its error against K1) and C5 whole on
         # this GPU (= the per-GPU shard of a 1-rank job); N GPUs: C5 split over the ranks (strong scaling)
-        todo = [("C5", 10, 3)] if world > 1 else [("C2", 200, 20), ("C4", 100, 10), ("C3", 12, 3), ("C5", 10, 3)]
+        todo = [("C5", 10, 3)] if world > 1 else [("C3", 12, 3), ("C5", 10, 3), ("C2", 200, 20), ("C4", 100, 10)]
         for cfg, st, wu in todo:
             try:
                 r2, _ = measure(ctx, cfg, st, wu, events=False, breakdown=(cfg != "C2"))

@@ -125,7 +125,8 @@ int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const siz
                     const float *vals, const uint8_t *dones, const float *neglogps, size_t n,
                     size_t steps);
 /* add_experience with DEVICE source rows (device-resident simulators / policies);
- * dones_f32 already 0.0/1.0.  The six copies are ENQUEUED on the handle's stream and the call
+ * dones_f32 exactly 0.0 or 1.0 as the reference stores them (buffer.rs:95; the scans read the flags as
+ * bits, any non-zero value counts as done).  The six copies are ENQUEUED on the handle's stream and the call
  * returns without waiting: the source arrays must stay valid and unchanged until that stream has
  * passed them (ppo_xp_sync(), or an event recorded on ppo_xp_stream() after the call), and whatever
  * produced them must be ordered before the call (same stream, or synchronised).  The Python mirror
@@ -221,6 +222,10 @@ int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io);
  * shuffling on the caller's thread (the reference draws a fresh permutation per pass, training.rs:204-205:
  * prefetch pass i+1's while pass i trains).  Any other pass_begin simply discards it. */
 int ppo_xp_shuffle_prefetch(ppo_xp *h, uint64_t seed);
+/* Which kernels gathered the current pass: 0 = scalar_gather_kernel + obs_gather_kernel, 1 = fused_gather_kernel
+ * (rows and scalar streams in one launch; chosen by size, see the "fused" tunable), -1 = no pass.  For
+ * measurement harnesses that attribute bytes to kernels. */
+int ppo_xp_pass_gather_kind(const ppo_xp *h);
 /* Number of minibatches of the current pass (ExperienceBatcher::len()/B rounded up). */
 size_t ppo_xp_pass_num_batches(const ppo_xp *h);
 /* The permutation of the current pass on the device (u32[M]) / copied to the host. */
@@ -299,7 +304,9 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * minibatch skip the finalize launch: the standardise workgroups add the tile sums themselves),
  * "gae_waves" 0 (auto)/1/2/4/8/16 (waves per 64 envs of the sequential scan), "gae_unroll" 0 (auto)/4/8/16,
  * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams),
- * "gae_flat" 0/1 (1: the packing scan always stores the flat returns / advantages arrays too).
+ * "gae_flat" 0/1 (1: the packing scan always stores the flat returns / advantages arrays too),
+ * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),
+ * "fused_block" 256/512 (its workgroup size).
  * Unknown names or values => PPO_XP_EINVAL. */
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
 

@@ -79,6 +79,7 @@ SYMBOLS = {
     "ppo_xp_pass_next": (_i, [_vp, C.POINTER(BatchView)]),
     "ppo_xp_pass_next_host": (_i, [_vp, C.POINTER(BatchHost)]),
     "ppo_xp_shuffle_prefetch": (_i, [_vp, _u64]),
+    "ppo_xp_pass_gather_kind": (_i, [_vp]),
     "ppo_xp_pass_num_batches": (_sz, [_vp]),
     "ppo_xp_pass_perm_device": (_vp, [_vp]),
     "ppo_xp_pass_perm_host": (_i, [_vp, _vp, _sz]),

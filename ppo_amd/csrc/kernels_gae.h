@@ -15,34 +15,57 @@
 
 namespace ppoxp {
 
-// Packed per-transition record read by the scalar gather: ONE 16-byte access per gathered row
-// instead of four scattered 4/8-byte reads (values, neglogps, returns, actions).  adv' is not
-// stored: the gather recomputes fl(ret - v), the very operation of data.rs:62.
+// Packed per-transition records read by the scalar gather: ONE 128-byte line fetch per gathered row instead
+// of four scattered 4/8-byte reads (values, neglogps, returns, actions).  adv' is not stored: the gather
+// recomputes fl(ret - v), the very operation of data.rs:62.
+//
+// A record line holds 8 consecutive transitions (flat index i = t*N + e, line i/8, slot i%8):
+//   bytes [ 0,  64): eight STATIC halves {nlp, act32}  — known when the row is inserted (buffer.rs:93-113),
+//                    written by pack_static_kernel at insert time, outside the timed path;
+//   bytes [64, 128): eight SCAN halves   {v, ret}      — written by the GAE scan, 64 contiguous aligned
+//                    bytes per 8 lanes, i.e. full 64-byte write requests.
+// So the scan moves exactly its algorithmic 20 B per transition (12 read + 8 written) and never touches
+// neglogps / actions, and a gathered row still costs one line.
 // Actions are usize in the reference (buffer.rs:33).  The record keeps the low 32 bits; an action
 // that does not fit (or equals the escape value itself) is stored as kRecActEscape and the gather
 // fetches the full 64-bit value from the actions stream for that one row.
-struct __attribute__((aligned(16))) Rec {
-  float v, nlp, ret;
-  uint32_t act;
-};
-static_assert(sizeof(Rec) == 16, "Rec must be 16 bytes");
+struct __attribute__((aligned(8))) RecHalf { uint32_t x, y; };
+typedef RecHalf Rec;
+static_assert(sizeof(RecHalf) == 8, "RecHalf must be 8 bytes");
 constexpr uint32_t kRecActEscape = 0xFFFFFFFFu;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void store_rec(Rec *dst, float v, float nlp, float ret, int64_t act) {
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+// index, in RecHalf units, of the static half of transition i; its scan half is 8 further
+__host__ __device__ __forceinline__ size_t rec_static_idx(size_t i) { return ((i >> 3) << 4) + (i & 7); }
+__host__ __device__ __forceinline__ size_t rec_halves(size_t transitions) { return ((transitions + 7) >> 3) << 4; }
+
+__device__ __forceinline__ void store_rec_scan(Rec *rec, size_t i, float v, float ret) {
+  u32x2_t q;
+  q.x = __float_as_uint(v); q.y = __float_as_uint(ret);
+  *reinterpret_cast<u32x2_t *>(rec + rec_static_idx(i) + 8) = q;
+}
+__device__ __forceinline__ void store_rec_static(Rec *rec, size_t i, float nlp, int64_t act) {
   const uint64_t a = (uint64_t)act;
-  u32x4_t q;
-  q.x = __float_as_uint(v); q.y = __float_as_uint(nlp); q.z = __float_as_uint(ret);
-  q.w = a >= (uint64_t)kRecActEscape ? kRecActEscape : (uint32_t)a;
-  *reinterpret_cast<u32x4_t *>(dst) = q;
+  u32x2_t q;
+  q.x = __float_as_uint(nlp);
+  q.y = a >= (uint64_t)kRecActEscape ? kRecActEscape : (uint32_t)a;
+  *reinterpret_cast<u32x2_t *>(rec + rec_static_idx(i)) = q;
+}
+__device__ __forceinline__ void load_rec_scan(const Rec *rec, size_t i, float &v, float &ret) {
+  const u32x2_t q = *reinterpret_cast<const u32x2_t *>(rec + rec_static_idx(i) + 8);
+  v = __uint_as_float(q.x); ret = __uint_as_float(q.y);
 }
 
 struct GaeArgs {
-  const float *rewards, *values, *dones, *neglogps;  // [T, N]
-  const int64_t *actions;                            // [T, N]
+  const float *rewards, *values;                     // [T, N]
+  const uint32_t *done_bits;                         // [T, W] W = ceil(N/32): bit e%32 of word e/32 = dones[t, e] != 0,
+                                                     // kept in step with the f32 dones stream by the insert entry points
+                                                     // (pack_done_bits_kernel): the scan reads 8 bytes per wave and step
+                                                     // instead of 256; 1 - d is exactly 1.0f / 0.0f for d in {0, 1}
+  unsigned W;
   const uint8_t *last_dones;                         // [N] Rust bools
   float *returns, *adv;                              // [T*N]
-  Rec *rec;                                          // [T*N]
+  Rec *rec;                                          // record lines of [T*N] transitions (scan halves written here)
   const float *carry;                                // [C, N] chunk carry-in (assoc) or nullptr
   float *sumP, *sumQ;                                // [C, N] chunk summaries (assoc)
   unsigned N, len, lvi, chunk;                       // chunk = time steps per blockIdx.y
@@ -52,6 +75,10 @@ struct GaeArgs {
                                                      // a pass reads only the records, so the packing scan skips these 8 B per
                                                      // transition unless a caller asked for the arrays (ppo_xp_views & co.)
 };
+
+// nonterminal factor 1 - dones[t, e] (buffer.rs:199) from the packed done bits
+__device__ __forceinline__ uint32_t done_word(const GaeArgs &a, size_t t, unsigned e) { return a.done_bits[t * a.W + (e >> 5)]; }
+__device__ __forceinline__ float nnt_of(uint32_t word, unsigned e) { return ((word >> (e & 31u)) & 1u) ? 0.0f : 1.0f; }
 
 // One time step of buffer.rs:217-222, in the reference's rounding order.
 __device__ __forceinline__ void gae_step(float r, float v, float v_next, float nnt_next, float gamma,
@@ -91,13 +118,13 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
     A = 0.0f;                                  // buffer.rs:196
   } else {                                     // buffer.rs:212-213, 199
     v_next = a.values[(size_t)(t_hi + 1) * N + e];
-    nnt_next = 1.0f - a.dones[(size_t)(t_hi + 1) * N + e];
+    nnt_next = nnt_of(done_word(a, (size_t)(t_hi + 1), e), e);
     A = SUMMARY ? 0.0f : a.carry[(size_t)c * N + e];
   }
   float P = 1.0f;
 
-  float r[U], v[U], d[U], nl[U];
-  int64_t ac[U];
+  float r[U], v[U];
+  uint32_t d[U];                               // done words (wave-uniform pairs: 8 bytes per wave and step)
   auto load = [&](int t_top) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -106,23 +133,20 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
       if (a.nt) {   // wave-uniform: streams read once must not push the records out of the Infinity Cache
         r[u] = __builtin_nontemporal_load(a.rewards + i);
         v[u] = __builtin_nontemporal_load(a.values + i);
-        d[u] = __builtin_nontemporal_load(a.dones + i);
-        if (PACK) { nl[u] = __builtin_nontemporal_load(a.neglogps + i); ac[u] = __builtin_nontemporal_load(a.actions + i); }
       } else {
         r[u] = a.rewards[i];
         v[u] = a.values[i];
-        d[u] = a.dones[i];
-        if (PACK) { nl[u] = a.neglogps[i]; ac[u] = a.actions[i]; }
       }
+      d[u] = done_word(a, (size_t)t, e);
     }
   };
 
   load(t_hi);
   for (int t_top = t_hi; t_top >= t_lo; t_top -= U) {
-    float rc[U], vc[U], dc[U], nlc[U];
-    int64_t acc[U];
+    float rc[U], vc[U];
+    uint32_t dc[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { rc[u] = r[u]; vc[u] = v[u]; dc[u] = d[u]; if (PACK) { nlc[u] = nl[u]; acc[u] = ac[u]; } }
+    for (int u = 0; u < U; ++u) { rc[u] = r[u]; vc[u] = v[u]; dc[u] = d[u]; }
     if (t_top - U >= t_lo) load(t_top - U);    // prefetch the next U steps (wave-uniform)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -137,10 +161,10 @@ __global__ __launch_bounds__(64) void gae_scan_kernel(GaeArgs a) {
             if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
             else { a.returns[i] = ret; a.adv[i] = adv; }
           }
-          if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
+          if (PACK) store_rec_scan(a.rec, i, vc[u], ret);
         }
         v_next = vc[u];
-        nnt_next = 1.0f - dc[u];
+        nnt_next = nnt_of(dc[u], e);
       }
     }
   }
@@ -172,8 +196,8 @@ __global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
   const int len = (int)a.len;
   constexpr int span = W * S;
 
-  float r[S], v[S], d[S], nl[S], vb, db;      // vb, db: value / done flag of the row above the slice
-  int64_t ac[S];
+  float r[S], v[S], vb, db;                   // vb, db: value / done flag of the row above the slice
+  uint32_t d[S];                              // done words
   auto load = [&](int top) {                  // top = latest time step of this wave's slice (may be < 0: empty)
 #pragma unroll
     for (int u = 0; u < S; ++u) {
@@ -181,12 +205,10 @@ __global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
       if (a.nt) {
         r[u] = __builtin_nontemporal_load(a.rewards + i);
         v[u] = __builtin_nontemporal_load(a.values + i);
-        d[u] = __builtin_nontemporal_load(a.dones + i);
-        if (PACK) { nl[u] = __builtin_nontemporal_load(a.neglogps + i); ac[u] = __builtin_nontemporal_load(a.actions + i); }
       } else {
-        r[u] = a.rewards[i]; v[u] = a.values[i]; d[u] = a.dones[i];
-        if (PACK) { nl[u] = a.neglogps[i]; ac[u] = a.actions[i]; }
+        r[u] = a.rewards[i]; v[u] = a.values[i];
       }
+      d[u] = done_word(a, (size_t)max(top - u, 0), (unsigned)e);
     }
     if (top >= len - 1) {                     // buffer.rs:209-210, 201-204 (1 - 1 = 0, 1 - 0 = 1: same factors)
       vb = a.values[(size_t)a.lvi * N + e];
@@ -194,17 +216,17 @@ __global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
     } else {                                  // buffer.rs:212-213, 199
       const size_t i = (size_t)max(top + 1, 0) * N + e;
       vb = a.values[i];
-      db = a.dones[i];
+      db = 1.0f - nnt_of(done_word(a, (size_t)max(top + 1, 0), (unsigned)e), (unsigned)e);
     }
   };
 
   load(len - 1 - w * S);
   for (int sc_top = len - 1; sc_top >= 0; sc_top -= span) {
     const int top = sc_top - w * S;
-    float rc[S], vc[S], dc[S], nlc[S];
-    int64_t acc[S];
+    float rc[S], vc[S];
+    uint32_t dc[S];
 #pragma unroll
-    for (int u = 0; u < S; ++u) { rc[u] = r[u]; vc[u] = v[u]; dc[u] = d[u]; if (PACK) { nlc[u] = nl[u]; acc[u] = ac[u]; } }
+    for (int u = 0; u < S; ++u) { rc[u] = r[u]; vc[u] = v[u]; dc[u] = d[u]; }
     float v_next = vb, nnt_next = 1.0f - db;
     if (sc_top - span >= 0) load(sc_top - span - w * S);   // next super-chunk (workgroup-uniform)
 
@@ -217,7 +239,7 @@ __global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
       delta[u] = x3 - vc[u];
       nnt[u] = nnt_next;
       v_next = vc[u];
-      nnt_next = 1.0f - dc[u];
+      nnt_next = nnt_of(dc[u], (unsigned)e);
     }
 #pragma unroll 1
     for (int p = 0; p < W; ++p) {
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(64 * W) void gae_wide_kernel(GaeArgs a) {
               if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
               else { a.returns[i] = ret; a.adv[i] = adv; }
             }
-            if (PACK) store_rec(a.rec + i, vc[u], nlc[u], ret, acc[u]);
+            if (PACK) store_rec_scan(a.rec, i, vc[u], ret);
           }
         }
       }
@@ -312,16 +334,35 @@ __global__ __launch_bounds__(64 * W) void gae_carry_scan_kernel(const float *__r
   }
 }
 
-// Builds the packed records from the flat streams (only needed after a PPO_XP_GAE_NO_PACK
-// returns()).
+// Scan halves from the flat streams (only needed after a PPO_XP_GAE_NO_PACK returns()).
 __global__ __launch_bounds__(256) void pack_records_kernel(const float *__restrict__ values,
-                                                           const float *__restrict__ neglogps,
                                                            const float *__restrict__ returns,
-                                                           const int64_t *__restrict__ actions,
                                                            Rec *__restrict__ rec, size_t M) {
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
-    store_rec(rec + i, values[i], neglogps[i], returns[i], actions[i]);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x)
+    store_rec_scan(rec, i, values[i], returns[i]);
+}
+
+// Done bits of rows [row0, row0 + gridDim.y) from the f32 dones stream (0.0 / 1.0, buffer.rs:95): one wave per 64
+// envs, ballot -> two words.  grid = (ceil(N / 256), rows), block = 256.
+__global__ __launch_bounds__(256) void pack_done_bits_kernel(const float *__restrict__ dones, uint32_t *__restrict__ bits,
+                                                             unsigned N, unsigned W, size_t row0) {
+  const size_t t = row0 + blockIdx.y;
+  const unsigned e = blockIdx.x * 256u + threadIdx.x, e0 = e & ~63u;
+  const bool d = e < N && dones[t * N + e] != 0.0f;
+  const unsigned long long m = __ballot(d);
+  if ((threadIdx.x & 63u) == 0 && e0 < N) {
+    bits[t * W + (e0 >> 5)] = (uint32_t)m;
+    if ((e0 >> 5) + 1 < W) bits[t * W + (e0 >> 5) + 1] = (uint32_t)(m >> 32);
   }
+}
+
+// Static halves {nlp, act32} of transitions [i0, i0 + count): launched by the insert entry points right
+// after the rows have been copied into the buffer (buffer.rs:93-113), so they are always in step with it.
+__global__ __launch_bounds__(256) void pack_static_kernel(const float *__restrict__ neglogps,
+                                                          const int64_t *__restrict__ actions,
+                                                          Rec *__restrict__ rec, size_t i0, size_t count) {
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (size_t)gridDim.x * blockDim.x)
+    store_rec_static(rec, i0 + j, neglogps[i0 + j], actions[i0 + j]);
 }
 
 // The flat returns / adv' arrays from the records, for callers that ask for them after a packing
@@ -329,10 +370,9 @@ __global__ __launch_bounds__(256) void pack_records_kernel(const float *__restri
 // record as it was computed, adv' = fl(ret - v) is the very operation of data.rs:62.
 __global__ __launch_bounds__(256) void unpack_flat_kernel(const Rec *__restrict__ rec, float *__restrict__ returns,
                                                           float *__restrict__ adv, size_t M) {
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
-    const u32x4_t q = *reinterpret_cast<const u32x4_t *>(rec + i);
-    const float v = __uint_as_float(q.x), ret = __uint_as_float(q.z);
+    float v, ret;
+    load_rec_scan(rec, i, v, ret);
     returns[i] = ret;
     adv[i] = ret - v;
   }

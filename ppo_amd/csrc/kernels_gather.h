@@ -92,7 +92,7 @@ __global__ __launch_bounds__(BS) void obs_gather_kernel(ObsGatherArgs g) {
 }
 
 struct ScalarGatherArgs {
-  const Rec *rec;          // [M]
+  const Rec *rec;          // record lines of the M transitions (kernels_gae.h)
   const int64_t *actions;  // [M] (only read for actions that do not fit the record)
   const uint32_t *perm;    // [M]
   int64_t *act_out;        // [K*B]
@@ -126,11 +126,13 @@ __device__ __forceinline__ void scalar_gather_body(const ScalarGatherArgs &g, un
   if (valid) {
     uint32_t p = __builtin_nontemporal_load(g.perm + start + r);
     p = min(p, (uint32_t)(g.M - 1));
-    const u32x4 *rp = reinterpret_cast<const u32x4 *>(g.rec) + p;
-    const u32x4 q = g.rec_nt ? __builtin_nontemporal_load(rp) : *rp;
-    const float v = __uint_as_float(q.x), nlp = __uint_as_float(q.y), ret = __uint_as_float(q.z);
-    int64_t act = (int64_t)q.w;
-    if (q.w == kRecActEscape) act = g.actions[p];              // rare: action does not fit 32 bits
+    // the two halves of the record sit in one 128-byte line: one fetch, the second load hits
+    const u32x2_t *rp = reinterpret_cast<const u32x2_t *>(g.rec + rec_static_idx(p));
+    const u32x2_t qs = g.rec_nt ? __builtin_nontemporal_load(rp) : *rp;
+    const u32x2_t qd = g.rec_nt ? __builtin_nontemporal_load(rp + 8) : *(rp + 8);
+    const float nlp = __uint_as_float(qs.x), v = __uint_as_float(qd.x), ret = __uint_as_float(qd.y);
+    int64_t act = (int64_t)qs.y;
+    if (qs.y == kRecActEscape) act = g.actions[p];             // rare: action does not fit 32 bits
     adv = ret - v;                                            // data.rs:62 (same op as the GAE kernel's adv')
     const size_t o = (size_t)k * g.B + r;
     if (g.out_nt) {
@@ -166,40 +168,20 @@ __device__ __forceinline__ void scalar_gather_body(const ScalarGatherArgs &g, un
 // grid = K * tiles_per_mb workgroups of 256 threads.
 __global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) { scalar_gather_body<256>(g, blockIdx.x); }
 
-// Observation rows AND scalar streams in ONE launch: a grid of 64-thread workgroups in which every
-// (ratio+1)-th workgroup is a scalar tile (64 rows, lane = row) and the others are observation workgroups
-// exactly as in obs_gather_kernel (thread = one 16-byte element).  Both keep the shape that is fastest for
-// them on their own; being in one grid, the record lines (random 128-B fetches, latency bound, served by
-// the Infinity Cache while the records fit) travel under the observation rows' HBM stream instead of after
-// it.  nbo observation workgroups, nbs scalar tiles; workgroup b is a scalar tile iff
-// floor((b+1)*nbs/total) != floor(b*nbs/total), which spreads them evenly (and over all XCDs).
-struct MixedGatherArgs {
-  ObsGatherArgs o;
-  ScalarGatherArgs s;
-  unsigned long long nbo, nbs;
-};
-
-template <int V, bool NT, bool POW2, bool TAIL>
-__global__ __launch_bounds__(64) void mixed_gather_kernel(MixedGatherArgs g) {
-  const unsigned long long b = blockIdx.x, total = g.nbo + g.nbs;
-  const unsigned long long before = (b * g.nbs) / total;      // scalar tiles among workgroups [0, b)
-  if (((b + 1) * g.nbs) / total != before) scalar_gather_body<64>(g.s, (unsigned)before);
-  else obs_gather_body<V, 64, NT, POW2, TAIL>(g.o, (size_t)(b - before));
-}
-
-// EXPERIMENT (tunable "fused" = 1, D % 4 == 0, Q = D/4 a power of two <= 16, B % RPW == 0): observation rows
-// AND the scalar streams of RPW = 256/Q output rows in one workgroup.  Thread = one 16-byte element of one
-// row, as in obs_gather_kernel; the first RPW lanes of wave 0 also fetch the rows' records and store the
-// five scalar streams (RPW*4 contiguous bytes per stream) and the tile's fp64 (sum, sum of squares).
-// Purpose: the record lines (served by the Infinity Cache when the records fit it) travel while the
-// observation rows stream from HBM, instead of in a kernel of their own.
+// Observation rows AND the scalar streams of RPW = BS/Q output rows in one workgroup (D % 4 == 0, Q = D/4 a
+// power of two, RPW <= 64, B % RPW == 0).  Thread = one 16-byte element of one row, exactly as in
+// obs_gather_kernel; the first RPW lanes of wave 0 also fetch the rows' record lines and store the five
+// scalar streams (RPW*4 contiguous bytes per stream) and the tile's fp64 (sum, sum of squares).
+// Why: with BS = 512 and D = 64 a workgroup covers 32 rows = exactly one 128-byte line of the permutation,
+// which is then fetched once instead of by 8 workgroups on 8 XCDs (0.27 GB -> 0.03 GB at TGT), and the record
+// lines travel with the rows' stream instead of in a launch of their own: 839 us against 713 + 188 at TGT.
+// It only pays while the records (16 B x M) fit the Infinity Cache beside the stream; with 0.5 - 2 GB of
+// records (C3, C5 on one GPU) the random line fetches disturb the row stream and the split kernels win
+// (profiles/r2/ab_fused_*.log), so the host picks it by size.
 struct FusedGatherArgs {
   ObsGatherArgs o;
   ScalarGatherArgs s;
-  unsigned rpw;            // observation rows per workgroup = BS / Q
-  unsigned srows;          // scalar rows per workgroup (<= 64), a multiple of rpw: workgroup b gathers the scalar
-                           // streams of rows [b*srows, (b+1)*srows), so with srows = S*rpw the first 1/S of the grid
-                           // finishes them while the records are still in the Infinity Cache
+  unsigned rpw;            // rows per workgroup = BS / Q  (<= 64) = rows per statistics tile
 };
 
 template <int BS, bool NT, bool TAIL>
@@ -225,11 +207,10 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
       else *d = *s;
     }
   }
-  // ---- scalar streams: the first srows lanes of wave 0
-  const size_t srow0 = (size_t)blockIdx.x * g.srows;
-  if (threadIdx.x < 64 && srow0 < KB) {
-    const size_t row = srow0 + threadIdx.x;
-    const bool valid = threadIdx.x < g.srows && row < KB;
+  // ---- scalar streams of the workgroup's rows: the first rpw lanes of wave 0
+  if (threadIdx.x < 64 && row0 < KB) {
+    const size_t row = row0 + threadIdx.x;
+    const bool valid = threadIdx.x < rpw && row < KB;
     float adv = 0.f;
     if (valid) {
       size_t pos = row;
@@ -239,10 +220,11 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
       }
       uint32_t p = g.s.perm[pos];
       p = min(p, (uint32_t)(g.s.M - 1));
-      const u32x4 q = *(reinterpret_cast<const u32x4 *>(g.s.rec) + p);
-      const float v = __uint_as_float(q.x), nlp = __uint_as_float(q.y), ret = __uint_as_float(q.z);
-      int64_t act = (int64_t)q.w;
-      if (q.w == kRecActEscape) act = g.s.actions[p];
+      const u32x2_t *rp = reinterpret_cast<const u32x2_t *>(g.s.rec + rec_static_idx(p));
+      const u32x2_t qs = *rp, qd = *(rp + 8);
+      const float nlp = __uint_as_float(qs.x), v = __uint_as_float(qd.x), ret = __uint_as_float(qd.y);
+      int64_t act = (int64_t)qs.y;
+      if (qs.y == kRecActEscape) act = g.s.actions[p];
       adv = ret - v;                                          // data.rs:62
       __builtin_nontemporal_store(v, g.s.val_out + row);
       __builtin_nontemporal_store(nlp, g.s.nlp_out + row);
@@ -252,7 +234,7 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
     }
     const double a = valid ? (double)adv : 0.0;
     const double s1 = wave_sum(a), s2 = wave_sum(a * a);
-    if (threadIdx.x == 0) g.s.partials[blockIdx.x] = make_double2(s1, s2);   // tile = srows rows (B % srows == 0)
+    if (threadIdx.x == 0) g.s.partials[blockIdx.x] = make_double2(s1, s2);   // tile = the workgroup's rows (B % rpw == 0)
   }
 }
 
@@ -261,19 +243,17 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
 // every workgroup that runs it (finalize_stats_kernel, or each normalize workgroup when it folds the
 // partials itself) gets the same bits.
 __device__ __forceinline__ void reduce_partials(const double2 *__restrict__ partials, unsigned tiles_per_mb,
-                                                double *s1s, double *s2s, double &t1, double &t2) {
+                                                double (*red)[2], double &t1, double &t2) {
   double s1 = 0.0, s2 = 0.0;
   for (unsigned i = threadIdx.x; i < tiles_per_mb; i += 256u) {
     double2 p = partials[i];
     s1 += p.x; s2 += p.y;
   }
-  s1s[threadIdx.x] = s1; s2s[threadIdx.x] = s2;
+  s1 = wave_sum(s1); s2 = wave_sum(s2);                       // lanes, then the four waves: one barrier
+  if ((threadIdx.x & 63u) == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; }
   __syncthreads();
-  for (unsigned off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) { s1s[threadIdx.x] += s1s[threadIdx.x + off]; s2s[threadIdx.x] += s2s[threadIdx.x + off]; }
-    __syncthreads();
-  }
-  t1 = s1s[0]; t2 = s2s[0];
+  t1 = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
+  t2 = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
 }
 
 // sums[k] = (count, sum, sumsq) of minibatch k.  grid = K, block = 256.  Launched when the sums
@@ -282,15 +262,34 @@ __device__ __forceinline__ void reduce_partials(const double2 *__restrict__ part
 __global__ __launch_bounds__(256) void finalize_stats_kernel(const double2 *__restrict__ partials,
                                                              double *__restrict__ sums, unsigned tiles_per_mb,
                                                              size_t B) {
-  __shared__ double s1s[256], s2s[256];
+  __shared__ double red[4][2];
   const unsigned k = blockIdx.x;
   double t1, t2;
-  reduce_partials(partials + (size_t)k * tiles_per_mb, tiles_per_mb, s1s, s2s, t1, t2);
+  reduce_partials(partials + (size_t)k * tiles_per_mb, tiles_per_mb, red, t1, t2);
   if (threadIdx.x == 0) {
     sums[3 * k + 0] = (double)B;
     sums[3 * k + 1] = t1;
     sums[3 * k + 2] = t2;
   }
+}
+
+// First level of a two-level fold for minibatches with many small tiles (the fused gather writes one partial
+// per 32 rows): workgroup (g, k) adds tiles [256 g, 256 g + 256) of minibatch k in a fixed order and stores
+// partials2[k * G + g]; normalize_kernel<FOLD> then folds the G second-level partials.  grid = (G, K).
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const double2 *__restrict__ partials,
+                                                              double2 *__restrict__ partials2, unsigned tiles_per_mb) {
+  __shared__ double red[4][2];
+  const unsigned g = blockIdx.x, k = blockIdx.y, G = gridDim.x;
+  const unsigned i = g * 256u + threadIdx.x;
+  double2 p = make_double2(0.0, 0.0);
+  if (i < tiles_per_mb) p = partials[(size_t)k * tiles_per_mb + i];
+  const double s1 = wave_sum(p.x), s2 = wave_sum(p.y);
+  const unsigned w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0) { red[w][0] = s1; red[w][1] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    partials2[(size_t)k * G + g] = make_double2((red[0][0] + red[1][0]) + (red[2][0] + red[3][0]),
+                                                (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]));
 }
 
 // mean / unbiased std from (count, sum, sumsq) in fp64, then the reference's fp32 tail:
@@ -311,21 +310,29 @@ __device__ __forceinline__ void stats_from_sums(const double *s, float &mean, fl
 // per thread (16-byte accesses when the minibatch base allows it).
 // FOLD: no finalize_stats launch ran; every workgroup reduces the minibatch's `stat_tiles` partials
 // itself (same tree, same bits) and workgroup 0 of the minibatch also stores sums[k].
-template <bool FOLD>
+// VPT: 16-byte vectors per thread (a workgroup covers 1024 * VPT rows): the fold is paid once per workgroup, so
+// big minibatches use 4.
+template <bool FOLD, int VPT = 1>
 __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_out, double *__restrict__ sums,
                                                         const double2 *__restrict__ partials, unsigned stat_tiles,
                                                         float *__restrict__ stats, size_t B, unsigned tiles_per_mb) {
   const unsigned k = blockIdx.x / tiles_per_mb;
   const unsigned bx = blockIdx.x - k * tiles_per_mb;
   float *a = adv_out + (size_t)k * B;
-  const size_t j = ((size_t)bx * 256u + threadIdx.x) * 4u;
-  const bool vec = j + 4 <= B && ((reinterpret_cast<uintptr_t>(a + j) & 15u) == 0);
-  f32x4 x = {0.f, 0.f, 0.f, 0.f};
-  if (FOLD && vec) x = *reinterpret_cast<f32x4 *>(a + j);     // in flight while the partials are folded
+  size_t j[VPT];
+  bool vec[VPT];
+  f32x4 x[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    j[v] = (((size_t)bx * VPT + v) * 256u + threadIdx.x) * 4u;
+    vec[v] = j[v] + 4 <= B && ((reinterpret_cast<uintptr_t>(a + j[v]) & 15u) == 0);
+    x[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (FOLD && vec[v]) x[v] = *reinterpret_cast<f32x4 *>(a + j[v]);   // in flight while the partials are folded
+  }
   double s[3];
   if (FOLD) {
-    __shared__ double s1s[256], s2s[256];
-    reduce_partials(partials + (size_t)k * stat_tiles, stat_tiles, s1s, s2s, s[1], s[2]);
+    __shared__ double red[4][2];
+    reduce_partials(partials + (size_t)k * stat_tiles, stat_tiles, red, s[1], s[2]);
     s[0] = (double)B;
     if (bx == 0 && threadIdx.x == 0) { sums[3 * (size_t)k] = s[0]; sums[3 * (size_t)k + 1] = s[1]; sums[3 * (size_t)k + 2] = s[2]; }
   } else {
@@ -334,12 +341,16 @@ __global__ __launch_bounds__(256) void normalize_kernel(float *__restrict__ adv_
   float mean, stdv;
   stats_from_sums(s, mean, stdv);
   const float denom = stdv + 1e-8f;
-  if (vec) {
-    if (!FOLD) x = *reinterpret_cast<f32x4 *>(a + j);         // measured: loading first costs 2 us at TGT
-    x.x = (x.x - mean) / denom; x.y = (x.y - mean) / denom; x.z = (x.z - mean) / denom; x.w = (x.w - mean) / denom;
-    *reinterpret_cast<f32x4 *>(a + j) = x;
-  } else {
-    for (size_t i = j; i < B && i < j + 4; ++i) a[i] = (a[i] - mean) / denom;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    if (vec[v]) {
+      if (!FOLD) x[v] = *reinterpret_cast<f32x4 *>(a + j[v]);   // measured: loading first costs 2 us at TGT
+      f32x4 y = x[v];
+      y.x = (y.x - mean) / denom; y.y = (y.y - mean) / denom; y.z = (y.z - mean) / denom; y.w = (y.w - mean) / denom;
+      *reinterpret_cast<f32x4 *>(a + j[v]) = y;
+    } else {
+      for (size_t i = j[v]; i < B && i < j[v] + 4; ++i) a[i] = (a[i] - mean) / denom;
+    }
   }
   if (bx == 0 && threadIdx.x == 0) { stats[2 * (size_t)k] = mean; stats[2 * (size_t)k + 1] = stdv; }
 }
@@ -356,9 +367,9 @@ __global__ __launch_bounds__(256) void moments_kernel(const float *__restrict__ 
   for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < M; i += (size_t)gridDim.x * 256u) {
     double r, a;
     if (rec) {                                                  // kernel-uniform
-      const u32x4 q = *(reinterpret_cast<const u32x4 *>(rec) + i);
-      const float rf = __uint_as_float(q.z);
-      r = rf; a = rf - __uint_as_float(q.x);                    // data.rs:62 in fp32, then widened
+      float vf, rf;
+      load_rec_scan(rec, i, vf, rf);
+      r = rf; a = rf - vf;                                      // data.rs:62 in fp32, then widened
     } else {
       r = ret[i]; a = adv[i];
     }

@@ -134,6 +134,7 @@ struct ppo_xp {
   // GAE outputs
   float *returns = nullptr, *adv = nullptr;
   Rec *rec = nullptr;
+  uint32_t *done_bits = nullptr;   // [capacity, ceil(N/32)] the dones stream as bits, for the scans
   uint8_t *last_dones_dev = nullptr, *last_dones_pin = nullptr;  // pin: kPinSlots x N bytes
   hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool pin_used[4] = {false, false, false, false};
   unsigned pin_next = 0;
@@ -152,6 +153,7 @@ struct ppo_xp {
   double *sums = nullptr; float *stats = nullptr; size_t sums_cap = 0;
   size_t pass_B = 0, pass_K = 0, pass_M = 0, pass_iter = 0;
   bool pass_active = false, pass_pending_finish = false;
+  int pass_kind = 0;         // 0: scalar_gather_kernel + obs_gather_kernel, 1: fused_gather_kernel
   std::vector<uint32_t> perm_host;
   // Fisher-Yates of a coming pass drawn by a background thread (ppo_xp_shuffle_prefetch)
   std::thread pf_thread; std::vector<uint32_t> pf_perm; uint64_t pf_seed = 0; size_t pf_M = 0; bool pf_valid = false;
@@ -166,7 +168,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = 0, fused_block = 256, mixed = 0, fused_dense = 1;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512;
 };
 
 namespace {
@@ -222,9 +224,10 @@ template <bool PACK>
 int launch_gae_scan(ppo_xp *h, const GaeArgs &a, unsigned chunks) {
   dim3 grid((unsigned)((h->N + 63) / 64), chunks), block(64);
   ProfScope ps(h, PPO_XP_K_GAE);
-  // time steps in flight per wave: 8 when there are enough waves to cover the memory latency
-  // (TGT: 70 us vs 75 us with 16), 16 when the launch has at most one wave per CU (C2: 23 vs 25 us)
-  const long unroll = h->gae_unroll ? h->gae_unroll : ((size_t)grid.x * grid.y <= 256 ? 16 : 8);
+  // time steps in flight per wave.  Round 1 (the scan also carried neglogps / actions into the records): 8 at TGT,
+  // 16 for launches of at most one wave per CU.  Since the scan reads only r, v, d, 16 is never slower
+  // (TGT 38 us vs 44 with 8; C2 20.7 vs 24.6; C4 fix-up equal) — profiles/r2/tune_gae_r2.log
+  const long unroll = h->gae_unroll ? h->gae_unroll : 16;
   switch (unroll) {
     case 4: hipLaunchKernelGGL((gae_scan_kernel<PACK, 4>), grid, block, 0, h->stream, a); break;
     case 16: hipLaunchKernelGGL((gae_scan_kernel<PACK, 16>), grid, block, 0, h->stream, a); break;
@@ -240,7 +243,9 @@ unsigned pick_gae_waves(const ppo_xp *h, size_t len) {
   // 16.9 / 13.5 / 12.5 / 13.8 us with 2 / 4 / 8 / 16; TGT (1024 groups) 70.5 us with one wave, slower with more
   const size_t groups = (h->N + 63) / 64;
   unsigned w = 1;
-  while (w < 8 && groups * w < 512) w <<= 1;
+  // r2, scan without the record's static half: C3 (256 groups) 394 / 280 / 176 us with 1 / 2 / 4 waves, TGT (1024
+  // groups) 38 us with one wave and 16 steps in flight, 38 with two: aim at >= 1024 waves
+  while (w < 8 && groups * w < 1024) w <<= 1;
   while (w > 1 && (size_t)(w / 2) * 8 >= len) w >>= 1;   // no more waves than slices of 8 steps
   return w > 1 ? w : 0;
 }
@@ -270,8 +275,8 @@ int run_gae(ppo_xp *h, int algo, bool want_flat, float *static_scratch = nullptr
   const bool pack = !(algo & PPO_XP_GAE_NO_PACK);
   const int kind = algo & 0xff;
   GaeArgs a{};
-  a.rewards = h->rewards; a.values = h->values; a.dones = h->dones; a.neglogps = h->neglogps;
-  a.actions = h->actions; a.last_dones = h->last_dones_dev; a.returns = h->returns; a.adv = h->adv;
+  a.rewards = h->rewards; a.values = h->values; a.done_bits = h->done_bits; a.W = (unsigned)((N + 31) / 32);
+  a.last_dones = h->last_dones_dev; a.returns = h->returns; a.adv = h->adv;
   a.rec = h->rec; a.N = (unsigned)N; a.len = (unsigned)len; a.lvi = (unsigned)h->last_values_idx;
   a.gamma = h->gamma; a.nt = (int)h->gae_nt;
   a.flat = (!pack || want_flat || h->gae_flat) ? 1 : 0;
@@ -397,43 +402,6 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
   return launch_check("obs_gather_kernel");
 }
 
-template <int V>
-void launch_mixed_v(ppo_xp *h, const MixedGatherArgs &m, unsigned blocks, bool pow2, bool tail) {
-  dim3 grid(blocks), block(64);
-  if (pow2) {
-    if (tail) hipLaunchKernelGGL((mixed_gather_kernel<V, true, true, true>), grid, block, 0, h->stream, m);
-    else hipLaunchKernelGGL((mixed_gather_kernel<V, true, true, false>), grid, block, 0, h->stream, m);
-  } else {
-    if (tail) hipLaunchKernelGGL((mixed_gather_kernel<V, true, false, true>), grid, block, 0, h->stream, m);
-    else hipLaunchKernelGGL((mixed_gather_kernel<V, true, false, false>), grid, block, 0, h->stream, m);
-  }
-}
-
-int launch_mixed_gather(ppo_xp *h, const ScalarGatherArgs &sg, size_t K, size_t B, size_t M) {
-  const unsigned D = (unsigned)h->D;
-  const int V = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
-  MixedGatherArgs m{};
-  ObsGatherArgs &g = m.o;
-  g.obs = h->obs; g.perm = h->perm_cur; g.obs_out = h->obs_out; g.M = M; g.B = B;
-  g.Q = D / V;
-  g.total = K * B * g.Q;
-  const bool pow2 = (g.Q & (g.Q - 1)) == 0;
-  g.qshift = 0;
-  if (pow2) while ((1u << g.qshift) < g.Q) ++g.qshift;
-  const bool tail = K * B != M;
-  m.s = sg;
-  m.nbo = (g.total + 63) / 64;
-  m.nbs = (unsigned long long)K * sg.tiles_per_mb;
-  const unsigned long long blocks = m.nbo + m.nbs;
-  if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch (%llu workgroups)", blocks);
-  g.nblocks = (unsigned)m.nbo; g.xcd = 0;
-  ProfScope ps(h, PPO_XP_K_GATHER);
-  if (V == 4) launch_mixed_v<4>(h, m, (unsigned)blocks, pow2, tail);
-  else if (V == 2) launch_mixed_v<2>(h, m, (unsigned)blocks, pow2, tail);
-  else launch_mixed_v<1>(h, m, (unsigned)blocks, pow2, tail);
-  return launch_check("mixed_gather_kernel");
-}
-
 int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   // sized for this batch size at FULL capacity, so that a pass over a partly filled ring followed by
   // one over the full ring does not move the slabs (views of the earlier pass stay valid memory);
@@ -453,10 +421,12 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
     h->slab_rows = rows;
   }
   const size_t tiles = std::max(K, B <= Mcap ? (Mcap + B - 1) / B : (size_t)0) * ((B + tile_rows - 1) / tile_rows);
-  if (tiles > h->partials_cap) {
+  // + the second-level partials of reduce_partials_kernel (one per 256 tiles, rounded up per minibatch)
+  const size_t need = tiles + (tiles + 255) / 256 + std::max(K, (size_t)1);
+  if (need > h->partials_cap) {
     dev_free(h->partials); h->partials_cap = 0;
-    if (int rc = dev_alloc(&h->partials, tiles, false)) return rc;
-    h->partials_cap = tiles;
+    if (int rc = dev_alloc(&h->partials, need, false)) return rc;
+    h->partials_cap = need;
   }
   if (K > h->sums_cap) {
     dev_free(h->sums); dev_free(h->stats); h->sums_cap = 0;
@@ -468,19 +438,22 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
 }
 
 // fold = true: no finalize_stats launch preceded; the normalize workgroups reduce the partials themselves.
-int pass_finish_impl(ppo_xp *h, bool fold = false, unsigned fold_stat_tiles = 0) {
+int pass_finish_impl(ppo_xp *h, bool fold = false, unsigned fold_stat_tiles = 0, const double2 *fold_partials = nullptr) {
   const size_t K = h->pass_K, B = h->pass_B;
   if (K == 0) { h->pass_pending_finish = false; return 0; }
-  const size_t nbx = (B + 1023) / 1024;
+  const unsigned vpt = (fold && B >= 65536) ? 4u : 1u;      // the fold is paid per workgroup: fewer, fatter ones for big minibatches
+  const size_t nbx = (B + 1024 * vpt - 1) / (1024 * vpt);
   if (K * nbx > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for the normalize launch");
   const unsigned stat_tiles = fold_stat_tiles ? fold_stat_tiles : (unsigned)((B + 255) / 256);
   ProfScope ps(h, PPO_XP_K_NORMALIZE);
-  if (fold)
-    hipLaunchKernelGGL(normalize_kernel<true>, dim3((unsigned)(K * nbx)), dim3(256), 0, h->stream, h->adv_out, h->sums,
-                       h->partials, stat_tiles, h->stats, B, (unsigned)nbx);
+  const double2 *fp = fold_partials ? fold_partials : h->partials;
+  const dim3 grid((unsigned)(K * nbx));
+  if (fold && vpt == 4)
+    hipLaunchKernelGGL((normalize_kernel<true, 4>), grid, dim3(256), 0, h->stream, h->adv_out, h->sums, fp, stat_tiles, h->stats, B, (unsigned)nbx);
+  else if (fold)
+    hipLaunchKernelGGL((normalize_kernel<true, 1>), grid, dim3(256), 0, h->stream, h->adv_out, h->sums, fp, stat_tiles, h->stats, B, (unsigned)nbx);
   else
-    hipLaunchKernelGGL(normalize_kernel<false>, dim3((unsigned)(K * nbx)), dim3(256), 0, h->stream, h->adv_out, h->sums,
-                       h->partials, stat_tiles, h->stats, B, (unsigned)nbx);
+    hipLaunchKernelGGL((normalize_kernel<false, 1>), grid, dim3(256), 0, h->stream, h->adv_out, h->sums, fp, stat_tiles, h->stats, B, (unsigned)nbx);
   h->pass_pending_finish = false;
   return launch_check("normalize_kernel");
 }
@@ -495,62 +468,62 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   const size_t K = h->pass_K;
   if (K == 0) return 0;
   if (K * ((B + 255) / 256) > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
-  // rows per statistics tile (= per workgroup of whichever kernel gathers the scalar streams)
+  // rows per statistics tile (= per workgroup of whichever kernel gathers the scalar streams).
+  // The fused kernel (rows + scalar streams in one workgroup) is taken on one GPU when a workgroup covers 8..64
+  // whole rows and the records fit the Infinity Cache beside the row stream (measured: TGT 134 MB wins 75 us,
+  // C3 0.5 GB and C5-on-one-GPU 2.1 GB lose); "fused" = 0 / 1 forces the choice, -1 decides by size.
   const unsigned Dq = (unsigned)h->D / 4;
   const unsigned FBq = (unsigned)h->fused_block;
-  const unsigned srows = Dq ? std::min(64u, (FBq / std::max(Dq, 1u)) * (unsigned)h->fused_dense) : 0u;
-  const bool fusable = h->fused && h->xmode == 0 && h->D % 4 == 0 && Dq >= 4 && Dq <= FBq && FBq / Dq <= 64 && (Dq & (Dq - 1)) == 0 &&
-                       srows && B % srows == 0;
-  const bool mixed = !fusable && h->mixed && K * ((B + 63) / 64) <= 0x3fffffffull;
-  const size_t tile_rows = fusable ? srows : mixed ? 64 : 256;
+  const unsigned rpw = (Dq && FBq % Dq == 0) ? FBq / Dq : 0u;
+  const bool fits_mall = rec_halves(M) * sizeof(Rec) <= (size_t(160) << 20);
+  const bool fusable = h->fused != 0 && h->xmode == 0 && h->D % 4 == 0 && (Dq & (Dq - 1)) == 0 && rpw >= 8 && rpw <= 64 &&
+                       B % rpw == 0 && K <= 65535 && (h->fused == 1 || fits_mall);
+  const size_t tile_rows = fusable ? rpw : 256;
   if (int rc = ensure_pass_buffers(h, K, B, tile_rows)) return rc;
   if (!h->have_rec) {
     ProfScope ps(h, PPO_XP_K_PACK);
     unsigned blocks = (unsigned)std::min<size_t>((M + 255) / 256, 0x7fffffffull);
-    hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, h->stream, h->values, h->neglogps,
-                       h->returns, h->actions, h->rec, M);
+    hipLaunchKernelGGL(pack_records_kernel, dim3(blocks), dim3(256), 0, h->stream, h->values, h->returns, h->rec, M);
     if (int rc = launch_check("pack_records_kernel")) return rc;
     h->have_rec = true;
   }
-  {
-    // EXPERIMENT: one kernel for rows and scalar streams (see fused_gather_kernel)
-    const unsigned Q = Dq;
-    const unsigned FB = FBq;
-    if (fusable) {
-      FusedGatherArgs f{};
-      f.rpw = FB / Q; f.srows = srows;
-      f.o.obs = h->obs; f.o.perm = h->perm_cur; f.o.obs_out = h->obs_out; f.o.M = M; f.o.B = B; f.o.Q = Q;
-      f.o.total = K * B * Q; f.o.qshift = 0;
-      while ((1u << f.o.qshift) < Q) ++f.o.qshift;
-      f.s.rec = h->rec; f.s.actions = h->actions; f.s.perm = h->perm_cur; f.s.act_out = h->act_out;
-      f.s.val_out = h->val_out; f.s.nlp_out = h->nlp_out; f.s.ret_out = h->ret_out; f.s.adv_out = h->adv_out;
-      f.s.partials = h->partials; f.s.M = M; f.s.B = B; f.s.tiles_per_mb = (unsigned)(B / srows);
-      const size_t blocks = K * (B / f.rpw);
-      if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
-      {
-        ProfScope ps(h, PPO_XP_K_GATHER);
-        const bool tail = K * B != M;
-        const dim3 grid((unsigned)blocks);
-        if (FB == 256) {
-          if (tail) hipLaunchKernelGGL((fused_gather_kernel<256, true, true>), grid, dim3(256), 0, h->stream, f);
-          else hipLaunchKernelGGL((fused_gather_kernel<256, true, false>), grid, dim3(256), 0, h->stream, f);
-        } else if (FB == 512) {
-          if (tail) hipLaunchKernelGGL((fused_gather_kernel<512, true, true>), grid, dim3(512), 0, h->stream, f);
-          else hipLaunchKernelGGL((fused_gather_kernel<512, true, false>), grid, dim3(512), 0, h->stream, f);
-        } else {
-          if (tail) hipLaunchKernelGGL((fused_gather_kernel<1024, true, true>), grid, dim3(1024), 0, h->stream, f);
-          else hipLaunchKernelGGL((fused_gather_kernel<1024, true, false>), grid, dim3(1024), 0, h->stream, f);
-        }
-        if (int rc = launch_check("fused_gather_kernel")) return rc;
+  h->pass_kind = fusable ? 1 : 0;
+  if (fusable) {
+    FusedGatherArgs f{};
+    f.rpw = rpw;
+    f.o.obs = h->obs; f.o.perm = h->perm_cur; f.o.obs_out = h->obs_out; f.o.M = M; f.o.B = B; f.o.Q = Dq;
+    f.o.total = K * B * Dq; f.o.qshift = 0;
+    while ((1u << f.o.qshift) < Dq) ++f.o.qshift;
+    f.s.rec = h->rec; f.s.actions = h->actions; f.s.perm = h->perm_cur; f.s.act_out = h->act_out;
+    f.s.val_out = h->val_out; f.s.nlp_out = h->nlp_out; f.s.ret_out = h->ret_out; f.s.adv_out = h->adv_out;
+    f.s.partials = h->partials; f.s.M = M; f.s.B = B; f.s.tiles_per_mb = (unsigned)(B / rpw);
+    const size_t blocks = K * (B / rpw);
+    if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
+    {
+      ProfScope ps(h, PPO_XP_K_GATHER);
+      const bool tail = K * B != M;
+      const dim3 grid((unsigned)blocks);
+      if (FBq == 256) {
+        if (tail) hipLaunchKernelGGL((fused_gather_kernel<256, true, true>), grid, dim3(256), 0, h->stream, f);
+        else hipLaunchKernelGGL((fused_gather_kernel<256, true, false>), grid, dim3(256), 0, h->stream, f);
+      } else {
+        if (tail) hipLaunchKernelGGL((fused_gather_kernel<512, true, true>), grid, dim3(512), 0, h->stream, f);
+        else hipLaunchKernelGGL((fused_gather_kernel<512, true, false>), grid, dim3(512), 0, h->stream, f);
       }
-      {
-        ProfScope ps(h, PPO_XP_K_FINALIZE);
-        hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
-                           f.s.tiles_per_mb, B);
-        if (int rc = launch_check("finalize_stats_kernel")) return rc;
-      }
-      return pass_finish_impl(h, false);
+      if (int rc = launch_check("fused_gather_kernel")) return rc;
     }
+    // statistics: few tiles per minibatch -> every standardise workgroup folds them itself; many -> one
+    // launch folds groups of 256 first (fixed order either way: deterministic)
+    const unsigned tiles = f.s.tiles_per_mb;
+    if (tiles <= 1024u) return pass_finish_impl(h, true, tiles);
+    const unsigned G = (tiles + 255u) / 256u;
+    double2 *partials2 = h->partials + K * (size_t)tiles;
+    {
+      ProfScope ps(h, PPO_XP_K_FINALIZE);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(G, (unsigned)K), dim3(256), 0, h->stream, h->partials, partials2, tiles);
+      if (int rc = launch_check("reduce_partials_kernel")) return rc;
+    }
+    return pass_finish_impl(h, true, G, partials2);
   }
   // scalar streams + statistics first (the records were just written by the GAE kernel and are
   // the most likely bytes to still sit in the Infinity Cache), observation rows after
@@ -559,23 +532,6 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   g.val_out = h->val_out; g.nlp_out = h->nlp_out; g.ret_out = h->ret_out; g.adv_out = h->adv_out;
   g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256);
   g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
-  if (mixed) {
-    // rows and scalar streams in one grid of 64-thread workgroups (mixed_gather_kernel)
-    g.tiles_per_mb = (unsigned)((B + 63) / 64);
-    if (int rc = launch_mixed_gather(h, g, K, B, M)) return rc;
-    const bool fold = h->xmode == 0 && g.tiles_per_mb <= (unsigned)h->fold_tiles;
-    if (!fold) {
-      ProfScope ps(h, PPO_XP_K_FINALIZE);
-      hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
-                         g.tiles_per_mb, B);
-      if (int rc = launch_check("finalize_stats_kernel")) return rc;
-    }
-    if (h->xmode == 0) return pass_finish_impl(h, fold, g.tiles_per_mb);
-    if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
-    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
-    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
-    return pass_finish_impl(h);
-  }
   {
     ProfScope ps(h, PPO_XP_K_SCALARS);
     hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
@@ -660,7 +616,8 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
   if (!rc) rc = dev_alloc(&h->neglogps, cn, true);
   if (!rc) rc = dev_alloc(&h->returns, cn, true);
   if (!rc) rc = dev_alloc(&h->adv, cn, true);
-  if (!rc) rc = dev_alloc(&h->rec, cn, true);
+  if (!rc) rc = dev_alloc(&h->rec, rec_halves(cn), true);   // zeros = the static halves of the zero-filled streams
+  if (!rc) rc = dev_alloc(&h->done_bits, capacity * ((num_envs + 31) / 32), true);
   if (!rc) rc = dev_alloc(&h->perm, cn, true);
   if (!rc) rc = dev_alloc(&h->last_dones_dev, num_envs, true);
   if (!rc && hipHostMalloc((void **)&h->last_dones_pin, 4 * std::max<size_t>(num_envs, 1), hipHostMallocDefault) != hipSuccess)
@@ -687,7 +644,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
   dev_free(h->obs); dev_free(h->rewards); dev_free(h->actions); dev_free(h->values); dev_free(h->dones);
-  dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->perm);
+  dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->done_bits); dev_free(h->perm);
   dev_free(h->last_dones_dev); dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
   dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out);
   dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
@@ -696,6 +653,23 @@ void ppo_xp_destroy(ppo_xp *h) {
   if (h->last_dones_pin) (void)hipHostFree(h->last_dones_pin);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+// The static halves {nlp, act32} of the record lines of rows [row, row + rows), from the rows just copied in.
+static int pack_static_rows(ppo_xp *h, size_t row, size_t rows) {
+  const size_t count = rows * h->N;
+  if (!count) return 0;
+  const unsigned blocks = (unsigned)std::min<size_t>((count + 255) / 256, 1u << 16);
+  hipLaunchKernelGGL(pack_static_kernel, dim3(blocks), dim3(256), 0, h->stream, h->neglogps, h->actions, h->rec, row * h->N, count);
+  if (int rc = launch_check("pack_static_kernel")) return rc;
+  const unsigned W = (unsigned)((h->N + 31) / 32);
+  for (size_t r0 = 0; r0 < rows; r0 += 65535) {     // gridDim.y limit
+    const unsigned ny = (unsigned)std::min<size_t>(rows - r0, 65535);
+    hipLaunchKernelGGL(pack_done_bits_kernel, dim3((unsigned)((h->N + 255) / 256), ny), dim3(256), 0, h->stream, h->dones,
+                       h->done_bits, (unsigned)h->N, W, row + r0);
+    if (int rc = launch_check("pack_done_bits_kernel")) return rc;
+  }
+  return 0;
 }
 
 static void advance_counter(ppo_xp *h, size_t idx) {
@@ -731,6 +705,7 @@ int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const siz
     HIP_TRY(hipMemcpyAsync(h->values + idx * N, vals + s * N, run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->dones + idx * N, donesf.data(), run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(hipMemcpyAsync(h->neglogps + idx * N, neglogps + s * N, run * N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    if (int rc = pack_static_rows(h, idx, run)) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));                    // host buffers are the caller's again
     for (size_t r = 0; r < run; ++r) advance_counter(h, idx + r);
     s += run;
@@ -756,6 +731,7 @@ int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const i
   HIP_TRY(hipMemcpyAsync(h->values + idx * N, vals, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->dones + idx * N, dones_f32, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   HIP_TRY(hipMemcpyAsync(h->neglogps + idx * N, neglogps, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  if (int rc = pack_static_rows(h, idx, 1)) return rc;
   advance_counter(h, idx);
   return 0;
 }
@@ -1005,6 +981,7 @@ int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io) {
   return 0;
 }
 
+int ppo_xp_pass_gather_kind(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_kind : -1; }
 size_t ppo_xp_pass_num_batches(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_K : 0; }
 const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *h) { return h ? h->perm_cur : nullptr; }
 
@@ -1129,10 +1106,8 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
   else if (n == "gae_flat" && (value == 0 || value == 1)) h->gae_flat = value;
-  else if (n == "fused" && (value == 0 || value == 1)) h->fused = value;
-  else if (n == "mixed" && (value == 0 || value == 1)) h->mixed = value;
-  else if (n == "fused_dense" && (value == 1 || value == 2 || value == 4 || value == 8)) h->fused_dense = value;
-  else if (n == "fused_block" && (value == 256 || value == 512 || value == 1024)) h->fused_block = value;
+  else if (n == "fused" && value >= -1 && value <= 1) h->fused = value;
+  else if (n == "fused_block" && (value == 256 || value == 512)) h->fused_block = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16)) h->gae_unroll = value;

@@ -1,6 +1,6 @@
 """Seeded random sweep of the whole path against the oracle: buffer shapes (ragged N, odd D, partial
 and wrapped rings), batch sizes (one row .. larger than the buffer), every GAE algorithm and scan
-shape, both gather block sizes, library-drawn / caller-supplied permutations.  Every case goes through
+shape, both gather block sizes, the split and the fused gather, library-drawn / caller-supplied permutations.  Every case goes through
 tests/test_gpu_parity.check_pass, i.e. the same bit-exact / stated-tolerance bars."""
 import numpy as np
 import pytest
@@ -22,6 +22,8 @@ def _case(g):
     B = 1 if r < 0.05 else M if r < 0.15 else M + 1 if r < 0.2 else int(g.integers(1, M + 1))
     if B == 1 and M > 3000:
         B = 7       # K = M one-row minibatches is covered elsewhere; keep the sweep quick
+    if D in (32, 64, 128, 256) and M >= 64 and g.random() < 0.6:
+        B = 64 * int(g.integers(1, M // 64 + 1))    # shapes the fused rows+scalars gather accepts (B % rows-per-workgroup == 0)
     return cap, steps, N, D, B
 
 
@@ -38,6 +40,8 @@ def test_random_configurations(xp, oracle, chunk):
         buf.set_tunable("gae_waves", int(g.choice([0, 1, 2, 4, 8, 16])))
         buf.set_tunable("gather_block", int(g.choice([64, 256])))
         buf.set_tunable("fold_tiles", int(g.choice([0, 256])))
+        buf.set_tunable("fused", int(g.choice([-1, 0, 1])))
+        buf.set_tunable("fused_block", int(g.choice([256, 512])))
         M = len(orc) * N
         perm = None
         seed = int(g.integers(1 << 62))

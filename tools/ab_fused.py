@@ -23,8 +23,8 @@ perm = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, 0
 buf.sync()
 outs = {}
 for fused in (0, 1, 2):
-    buf.set_tunable("fused", 1 if fused == 1 else 0)
-    buf.set_tunable("mixed", 1 if fused == 2 else 0)
+    buf.set_tunable("fused", 1 if fused else 0)
+    buf.set_tunable("fused_block", 256 if fused == 1 else 512)
     _lib.check(L.ppo_xp_returns(h, ldp, N, 0, None))
     it = ppo_amd.ExperienceBatcher(buf, B).into_iter(perm=perm)
     bs = list(it)
@@ -37,8 +37,7 @@ del outs
 res = {0: [], 1: []}
 wall = {0: [], 1: []}
 import time
-variants = {0: dict(fused=0, mixed=0), 1: dict(fused=1, fused_block=256, fused_dense=1), 2: dict(fused=1, fused_block=256, fused_dense=2),
-            3: dict(fused=1, fused_block=256, fused_dense=4), 4: dict(fused=1, fused_block=512, fused_dense=1), 5: dict(fused=1, fused_block=512, fused_dense=2)}
+variants = {0: dict(fused=0), 1: dict(fused=1, fused_block=256), 4: dict(fused=1, fused_block=512), 5: dict(fused=-1, fused_block=512)}
 res = {v: [] for v in variants}; wall = {v: [] for v in variants}
 for rnd in range(8):
     for fused, tun in variants.items():
