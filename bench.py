@@ -272,13 +272,19 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         step(i)
     barrier()
     fused = (not gae_only) and L.ppo_xp_pass_gather_kind(h) == 1
-    # timed region: HIP events only around the dominant kernel (an event pair costs ~7 us of stream time)
+    # timed region: HIP events only around the dominant kernel, and only on every 4th step (an event pair costs
+    # ~7 us of stream time: bracketing every launch would tax the very number it is there to explain)
     dom = "gae_scan" if gae_only else "gather"      # the dominant kernel of the step
-    buf.prof_enable([dom] if events else False)
+    buf.prof_enable(False)
     buf.prof_collect()
     t0 = time.perf_counter()
     for i in range(steps):
-        step(i)
+        if events and (i & 3) == 0:
+            buf.prof_enable([dom])
+            step(i)
+            buf.prof_enable(False)
+        else:
+            step(i)
     barrier()
     dt = time.perf_counter() - t0
     prof = buf.prof_collect()

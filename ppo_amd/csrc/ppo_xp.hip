@@ -135,9 +135,13 @@ struct ppo_xp {
   float *returns = nullptr, *adv = nullptr;
   Rec *rec = nullptr;
   uint32_t *done_bits = nullptr;   // [capacity, ceil(N/32)] the dones stream as bits, for the scans
-  uint8_t *last_dones_dev = nullptr, *last_dones_pin = nullptr;  // pin: kPinSlots x N bytes
-  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool pin_used[4] = {false, false, false, false};
+  // last_dones of ppo_xp_returns: a ring of 8 page-locked host slots of N bytes that the scan kernels read IN
+  // PLACE (mapped host memory: 64 bytes per wave, once): no copy command and its two queue gaps per call.  A slot
+  // is reused 8 calls later; one event per 4 calls (two alternate) tells when those scans have run.
+  uint8_t *last_dones_pin = nullptr, *last_dones_pin_dev = nullptr;
+  hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};
   unsigned pin_next = 0;
+  const uint8_t *last_dones_cur = nullptr;   // device address of the slot of the current call
   float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
   size_t scan_cap = 0;       // elements allocated in carry/sumP/sumQ
   bool have_returns = false, have_rec = false;
@@ -276,7 +280,7 @@ int run_gae(ppo_xp *h, int algo, bool want_flat, float *static_scratch = nullptr
   const int kind = algo & 0xff;
   GaeArgs a{};
   a.rewards = h->rewards; a.values = h->values; a.done_bits = h->done_bits; a.W = (unsigned)((N + 31) / 32);
-  a.last_dones = h->last_dones_dev; a.returns = h->returns; a.adv = h->adv;
+  a.last_dones = h->last_dones_cur; a.returns = h->returns; a.adv = h->adv;
   a.rec = h->rec; a.N = (unsigned)N; a.len = (unsigned)len; a.lvi = (unsigned)h->last_values_idx;
   a.gamma = h->gamma; a.nt = (int)h->gae_nt;
   a.flat = (!pack || want_flat || h->gae_flat) ? 1 : 0;
@@ -619,13 +623,14 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
   if (!rc) rc = dev_alloc(&h->rec, rec_halves(cn), true);   // zeros = the static halves of the zero-filled streams
   if (!rc) rc = dev_alloc(&h->done_bits, capacity * ((num_envs + 31) / 32), true);
   if (!rc) rc = dev_alloc(&h->perm, cn, true);
-  if (!rc) rc = dev_alloc(&h->last_dones_dev, num_envs, true);
-  if (!rc && hipHostMalloc((void **)&h->last_dones_pin, 4 * std::max<size_t>(num_envs, 1), hipHostMallocDefault) != hipSuccess)
+  if (!rc && hipHostMalloc((void **)&h->last_dones_pin, 8 * std::max<size_t>(num_envs, 1), hipHostMallocMapped) != hipSuccess)
     rc = fail(PPO_XP_ENOMEM, "create: hipHostMalloc failed");
+  if (!rc && hipHostGetDevicePointer((void **)&h->last_dones_pin_dev, h->last_dones_pin, 0) != hipSuccess)
+    rc = fail(PPO_XP_EIO, "create: hipHostGetDevicePointer failed");
   if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     rc = fail(PPO_XP_EIO, "create: hipStreamCreate failed");
   if (!rc) h->own_stream = true;
-  for (int i = 0; i < 4 && !rc; ++i)
+  for (int i = 0; i < 2 && !rc; ++i)
     if (hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(PPO_XP_EIO, "create: device sync failed");
   // set-up of the allocation-free entry point: this device's address of the static scratch
@@ -645,7 +650,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
   dev_free(h->obs); dev_free(h->rewards); dev_free(h->actions); dev_free(h->values); dev_free(h->dones);
   dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->done_bits); dev_free(h->perm);
-  dev_free(h->last_dones_dev); dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
+  dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
   dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out);
   dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
   dev_free(h->moments);
@@ -780,17 +785,20 @@ static int returns_impl(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo
   const int kind = algo & 0xff;
   if (kind != PPO_XP_GAE_SEQUENTIAL && kind != PPO_XP_GAE_ASSOC) return fail(PPO_XP_EINVAL, "returns: unknown algo %d", algo);
   HIP_TRY(hipSetDevice(h->device));
-  // pinned staging ring: wait only for the upload that used this slot four calls ago, so the
-  // host can keep enqueueing while the GPU still works on earlier calls
-  const unsigned slot = h->pin_next++ & 3u;
-  if (h->pin_used[slot]) HIP_TRY(hipEventSynchronize(h->pin_ev[slot]));
-  uint8_t *pin = h->last_dones_pin + (size_t)slot * n;
-  std::memcpy(pin, last_dones, n);
-  HIP_TRY(hipMemcpyAsync(h->last_dones_dev, pin, n, hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipEventRecord(h->pin_ev[slot], h->stream));
-  h->pin_used[slot] = true;
+  // slot ring (see the handle): calls 4b .. 4b+3 form block b; the event of block b is recorded after its last
+  // scan and waited for when block b+2 (which reuses its slots) starts
+  const unsigned call = h->pin_next++;
+  const unsigned slot = call & 7u, blk = (call >> 2) & 1u;
+  if ((call & 3u) == 0 && h->pin_used[blk]) HIP_TRY(hipEventSynchronize(h->pin_ev[blk]));
+  std::memcpy(h->last_dones_pin + (size_t)slot * n, last_dones, n);
+  h->last_dones_cur = h->last_dones_pin_dev + (size_t)slot * n;
   h->pass_active = false;
-  if (int rc = run_gae(h, algo, host_out != nullptr, static_scratch)) return rc;
+  const int grc = run_gae(h, algo, host_out != nullptr, static_scratch);
+  if ((call & 3u) == 3u) {          // also after a failed launch: the slots of this block may still be read
+    HIP_TRY(hipEventRecord(h->pin_ev[blk], h->stream));
+    h->pin_used[blk] = true;
+  }
+  if (grc) return grc;
   h->have_returns = true; h->ret_len = buf_len(h);
   if (buf_len(h) == 0) { h->have_rec = true; h->have_flat = true; }
   if (host_out) {
