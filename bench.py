@@ -179,6 +179,9 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         algo |= 0x100                         # PPO_XP_GAE_NO_PACK: no pass follows, no records needed
     seed = synth.SEEDS[cfg] + 1000 * rank
 
+    # an ordinary (non-NULL) stream for everything: the legacy NULL stream torch uses by default synchronises
+    # implicitly with every other blocking stream of the process
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
     buf = ppo_amd.ExperienceBuffer(N, D, T, device=ctx.local_rank)
     buf.use_torch_stream()                    # torch events / RCCL see the kernels' stream
     for t in tunables:
@@ -317,6 +320,8 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         L.ppo_xp_rccl_comm_destroy(comm)
     buf.close()
     del perms
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream(dev))
     torch.cuda.empty_cache()
 
     ms_per_step = dt / steps * 1e3

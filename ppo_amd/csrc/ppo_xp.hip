@@ -235,6 +235,7 @@ int launch_gae_scan(ppo_xp *h, const GaeArgs &a, unsigned chunks) {
   switch (unroll) {
     case 4: hipLaunchKernelGGL((gae_scan_kernel<PACK, 4>), grid, block, 0, h->stream, a); break;
     case 16: hipLaunchKernelGGL((gae_scan_kernel<PACK, 16>), grid, block, 0, h->stream, a); break;
+    case 32: hipLaunchKernelGGL((gae_scan_kernel<PACK, 32>), grid, block, 0, h->stream, a); break;
     default: hipLaunchKernelGGL((gae_scan_kernel<PACK, 8>), grid, block, 0, h->stream, a); break;
   }
   return launch_check("gae_scan_kernel");
@@ -480,7 +481,7 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   const unsigned FBq = (unsigned)h->fused_block;
   const unsigned rpw = (Dq && FBq % Dq == 0) ? FBq / Dq : 0u;
   const bool fits_mall = rec_halves(M) * sizeof(Rec) <= (size_t(160) << 20);
-  const bool fusable = h->fused != 0 && h->xmode == 0 && h->D % 4 == 0 && (Dq & (Dq - 1)) == 0 && rpw >= 8 && rpw <= 64 &&
+  const bool fusable = h->fused != 0 && h->D % 4 == 0 && (Dq & (Dq - 1)) == 0 && rpw >= 8 && rpw <= 64 &&
                        B % rpw == 0 && K <= 65535 && (h->fused == 1 || fits_mall);
   const size_t tile_rows = fusable ? rpw : 256;
   if (int rc = ensure_pass_buffers(h, K, B, tile_rows)) return rc;
@@ -519,15 +520,27 @@ int pass_begin_body(ppo_xp *h, size_t B) {
     // statistics: few tiles per minibatch -> every standardise workgroup folds them itself; many -> one
     // launch folds groups of 256 first (fixed order either way: deterministic)
     const unsigned tiles = f.s.tiles_per_mb;
-    if (tiles <= 1024u) return pass_finish_impl(h, true, tiles);
+    if (h->xmode == 0 && tiles <= 1024u) return pass_finish_impl(h, true, tiles);
     const unsigned G = (tiles + 255u) / 256u;
     double2 *partials2 = h->partials + K * (size_t)tiles;
-    {
+    const bool two_level = tiles > 1024u;
+    if (two_level) {
       ProfScope ps(h, PPO_XP_K_FINALIZE);
       hipLaunchKernelGGL(reduce_partials_kernel, dim3(G, (unsigned)K), dim3(256), 0, h->stream, h->partials, partials2, tiles);
       if (int rc = launch_check("reduce_partials_kernel")) return rc;
     }
-    return pass_finish_impl(h, true, G, partials2);
+    if (h->xmode == 0) return pass_finish_impl(h, true, G, partials2);
+    // sharded: this rank's (count, sum, sumsq) per minibatch must exist as numbers, they cross the ranks
+    {
+      ProfScope ps(h, PPO_XP_K_FINALIZE);
+      hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, two_level ? partials2 : h->partials,
+                         h->sums, two_level ? G : tiles, B);
+      if (int rc = launch_check("finalize_stats_kernel")) return rc;
+    }
+    if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
+    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+    return pass_finish_impl(h);
   }
   // scalar streams + statistics first (the records were just written by the GAE kernel and are
   // the most likely bytes to still sit in the Infinity Cache), observation rows after
@@ -1118,7 +1131,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "fused_block" && (value == 256 || value == 512)) h->fused_block = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
-  else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16)) h->gae_unroll = value;
+  else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32)) h->gae_unroll = value;
   else if (n == "carry_waves" && (value == 4 || value == 8 || value == 16)) h->carry_waves = value;
   else return fail(PPO_XP_EINVAL, "set_tunable: unknown name or bad value: %s = %ld", name, value);
   return 0;

@@ -28,11 +28,12 @@ def _fill(buf, r, sl=slice(None)):
                  c(r["dones"][:, sl]), c(r["neglogps"][:, sl]))
 
 
-def test_exchange_modes_agree_on_one_rank():
+@pytest.mark.parametrize("T,N,D,B", [(24, 96, 8, 500),        # scalar_gather_kernel + obs_gather_kernel
+                                     (16, 128, 64, 512)])     # fused_gather_kernel (32 rows per workgroup)
+def test_exchange_modes_agree_on_one_rank(T, N, D, B):
     import torch
     import ppo_amd
     from ppo_amd import _lib, synth
-    T, N, D, B = 24, 96, 8, 500
     r = synth.rollout(T, N, D, 77, 0.1)
     outs = []
     L = _lib.load()
@@ -51,6 +52,7 @@ def test_exchange_modes_agree_on_one_rank():
         elif mode == 2:
             buf.set_exchange(2)
         it = ppo_amd.ExperienceBatcher(buf, B).into_iter(seed=5)
+        assert L.ppo_xp_pass_gather_kind(buf.handle) == (1 if D == 64 else 0)
         if mode == 2:
             with pytest.raises(ppo_amd.PpoXpError):      # statistics not exchanged yet
                 next(it)

@@ -12,10 +12,13 @@ for root in sys.argv[1:]:
             name = row.get("Kernel_Name", "")
             if "ppoxp" not in name:
                 continue
-            short = name.split("ppoxp::")[1].split("(")[0].split("<")[0]
+            short = name.split("ppoxp::")[1].split("(")[0]
+            if not short.startswith("gae_scan_kernel"):      # the summary / fix-up / plain scans differ only by template arguments
+                short = short.split("<")[0]
+            short = short.replace(" ", "")
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k in sorted(acc):
     for c in sorted(acc[k]):
         v = acc[k][c]
         v = v[len(v) // 3:]  # drop warm-up dispatches
-        print(f"{k:28s} {c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+        print(f"{k:36s} {c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}")

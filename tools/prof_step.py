@@ -16,6 +16,9 @@ def main():
     import ppo_amd
     from ppo_amd import _lib, synth
     T, N, D, B = synth.CONFIGS[config]
+    if len(sys.argv) > 4:                 # fewer time steps of the same shape (the PMC tool does not survive 34 GB buffers)
+        T = int(sys.argv[4])
+        B = (T * N) // 32 if B else 0
     M = T * N
     if B == 0:
         B = M
@@ -25,10 +28,15 @@ def main():
     for kv in filter(None, os.environ.get("PPO_XP_TUNABLES", "").split(",")):   # e.g. fused=1,gae_flat=1
         k, v = kv.split("=")
         buf.set_tunable(k, int(v))
-    r = synth.rollout_device(T, N, D, 1, dev)
-    for t in range(T):
-        buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t], r["neglogps"][t])
-    ld = r["last_dones"].cpu().numpy()
+    if T > 4096:     # thousands of row inserts under --pmc crash the profiler: bulk-insert small rollouts from the host
+        r = synth.rollout(T, N, D, 1)
+        buf.add_many(r["obs"], r["rewards"], r["actions"], r["values"], r["dones"], r["neglogps"])
+        ld = r["last_dones"]
+    else:
+        r = synth.rollout_device(T, N, D, 1, dev)
+        for t in range(T):
+            buf.add_experience_device(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t], r["neglogps"][t])
+        ld = r["last_dones"].cpu().numpy()
     del r
     L, h = _lib.load(), buf.handle
     ldp = ld.ctypes.data_as(C.c_void_p)
