@@ -20,6 +20,7 @@
 
 #include "kernels_gae.h"
 #include "kernels_gather.h"
+#include "kernels_partition.h"
 #include "shuffle.h"
 #include "device_shuffle.h"
 #include "errors.h"
@@ -162,6 +163,7 @@ struct ppo_xp {
   // Fisher-Yates of a coming pass drawn by a background thread (ppo_xp_shuffle_prefetch)
   std::thread pf_thread; std::vector<uint32_t> pf_perm; uint64_t pf_seed = 0; size_t pf_M = 0; bool pf_valid = false;
   void *shuffle_ws = nullptr; size_t shuffle_ws_bytes = 0;   // device permutation generator workspace
+  void *part_ws = nullptr; size_t part_ws_bytes = 0;         // partitioned scalar path: counters, pairs, entries
   double *moments = nullptr;                                  // [kMomentBlocks][4] partials of explained_variance
   // exchange
   int xmode = 0; void *comm = nullptr;
@@ -172,7 +174,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0;
 };
 
 namespace {
@@ -407,6 +409,49 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
   return launch_check("obs_gather_kernel");
 }
 
+// The scalar streams through the partitioned path (kernels_partition.h): six streaming launches instead of one
+// kernel that fetches a 128-byte line per record.  Same outputs, same tile partials.
+int launch_partitioned_scalars(ppo_xp *h, const ScalarGatherArgs &g, size_t K, size_t B, size_t M) {
+  const unsigned nS = (unsigned)((M + (size_t(1) << kSrcShift) - 1) >> kSrcShift);
+  const unsigned nD = (unsigned)((M + (size_t(1) << kDstShift) - 1) >> kDstShift);
+  const size_t counters = (size_t)(nS + nD) * sizeof(uint32_t);
+  const size_t off_pairs = (counters + 255) & ~size_t(255);
+  const size_t off_entries = off_pairs + ((M * sizeof(uint2) + 255) & ~size_t(255));
+  const size_t need = off_entries + M * 5 * sizeof(uint32_t);
+  if (need > h->part_ws_bytes) {
+    if (h->part_ws) { HIP_TRY(hipStreamSynchronize(h->stream)); (void)hipFree(h->part_ws); h->part_ws = nullptr; h->part_ws_bytes = 0; }
+    HIP_TRY(hipMalloc(&h->part_ws, need));
+    h->part_ws_bytes = need;
+  }
+  char *ws = (char *)h->part_ws;
+  PartArgs a{};
+  a.perm = g.perm; a.M = M; a.rec = g.rec; a.actions = g.actions;
+  a.src_count = (uint32_t *)ws; a.dst_cursor = a.src_count + nS;
+  a.pairs = (uint2 *)(ws + off_pairs); a.entries = (uint32_t *)(ws + off_entries);
+  a.act_out = g.act_out; a.val_out = g.val_out; a.nlp_out = g.nlp_out; a.ret_out = g.ret_out; a.adv_out = g.adv_out;
+  a.nS = nS; a.nD = nD;
+  ProfScope ps(h, PPO_XP_K_SCALARS);
+  HIP_TRY(hipMemsetAsync(a.src_count, 0, (size_t)nS * sizeof(uint32_t), h->stream));
+  const unsigned chunks = (unsigned)((M + kPartChunk - 1) / kPartChunk);
+  hipLaunchKernelGGL(part_histogram_kernel, dim3(chunks), dim3(256), 0, h->stream, a);
+  hipLaunchKernelGGL(part_scan_kernel, dim3(1), dim3(1024), 0, h->stream, a);
+  hipLaunchKernelGGL(part_pairs_kernel, dim3(chunks), dim3(256), 0, h->stream, a);
+  {
+    const unsigned per_window = (1u << kSrcShift) / kPartChunk;
+    const unsigned windows = (chunks + per_window - 1) / per_window;
+    hipLaunchKernelGGL(part_records_kernel, dim3(((windows + 7) / 8) * 8 * per_window), dim3(1024), 0, h->stream, a);
+  }
+  {
+    const size_t c256 = (M + 255) / 256;
+    const unsigned per_window = (1u << kDstShift) / 256u;
+    const size_t windows = (c256 + per_window - 1) / per_window;
+    hipLaunchKernelGGL(part_scatter_kernel, dim3((unsigned)(((windows + 7) / 8) * 8 * per_window)), dim3(256), 0, h->stream, a);
+  }
+  hipLaunchKernelGGL(part_tile_stats_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g.adv_out, g.partials, B,
+                     g.tiles_per_mb);
+  return launch_check("partitioned scalar path");
+}
+
 int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   // sized for this batch size at FULL capacity, so that a pass over a partly filled ring followed by
   // one over the full ring does not move the slabs (views of the earlier pass stay valid memory);
@@ -549,7 +594,11 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   g.val_out = h->val_out; g.nlp_out = h->nlp_out; g.ret_out = h->ret_out; g.adv_out = h->adv_out;
   g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256);
   g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
-  {
+  const bool partitioned = h->scalar_path == 1 && K * B == M && M >= kPartChunk &&
+                           ((M + (size_t(1) << kSrcShift) - 1) >> kSrcShift) <= kMaxBins && ((M + (size_t(1) << kDstShift) - 1) >> kDstShift) <= kMaxBins;
+  if (partitioned) {
+    if (int rc = launch_partitioned_scalars(h, g, K, B, M)) return rc;
+  } else {
     ProfScope ps(h, PPO_XP_K_SCALARS);
     hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
     if (int rc = launch_check("scalar_gather_kernel")) return rc;
@@ -668,6 +717,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
   dev_free(h->moments);
   if (h->shuffle_ws) { (void)hipFree(h->shuffle_ws); h->shuffle_ws = nullptr; }
+  if (h->part_ws) { (void)hipFree(h->part_ws); h->part_ws = nullptr; }
   if (h->last_dones_pin) (void)hipHostFree(h->last_dones_pin);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -1129,6 +1179,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "gae_flat" && (value == 0 || value == 1)) h->gae_flat = value;
   else if (n == "fused" && value >= -1 && value <= 1) h->fused = value;
   else if (n == "fused_block" && (value == 256 || value == 512)) h->fused_block = value;
+  else if (n == "scalar_path" && (value == 0 || value == 1)) h->scalar_path = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32)) h->gae_unroll = value;

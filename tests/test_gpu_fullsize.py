@@ -71,8 +71,15 @@ def test_c2_full_oracle(oracle):
     buf.close()
 
 
+# |GPU - fp32-sequential restatement| allowed on a standardised advantage, by minibatch size.  The kernel sums in
+# fp64 (its distance to an fp64 evaluation stays < 2e-6 at every size); the reference's dfdx Cpu reduction is
+# restated as a SEQUENTIAL fp32 accumulate (order unpinned), whose own rounding error grows with
+# B: measured 2.6e-6 (B = 16 384, C2) ... see DESIGN.md section 2 for the full-size numbers.
+SEQ32_BOUND = {"TGT": 1e-3, "C3": 5e-3, "C5": 2e-3}
+
+
 @pytest.mark.parametrize("cfg", ["TGT", "C3", "C5/8"])
-def test_fullsize_properties(cfg):
+def test_fullsize_properties(cfg, oracle):
     """TGT; C3 (34 GB of observations, 1-KiB rows, the multi-wave scan); the per-GPU shard of C5 on 8 GPUs."""
     import torch
     import ppo_amd
@@ -109,6 +116,13 @@ def test_fullsize_properties(cfg):
         assert (b.advantages.double() - ref).abs().max().item() < 2e-6
         assert abs(b.advantages.double().mean().item()) < 1e-6
         assert abs(b.advantages.double().std(unbiased=True).item() - 1.0) < 1e-5
+        if k in (0, M // B - 1):
+            # what the reference itself would print for this minibatch, as far as it can be restated: the oracle's
+            # fp32-sequential standardisation (data.rs:157-164, 196-200) of the same gathered advantages, on the host
+            w32, _, _ = oracle.standardize(adv[idx].cpu().numpy())
+            d32 = float(np.abs(b.advantages.cpu().numpy() - w32).max())
+            print(f"{cfg}: minibatch {k} of {B} rows: max |GPU - fp32-sequential restatement| = {d32:.3e}")
+            assert d32 < SEQ32_BOUND[cfg], d32
         n += 1
     assert n == M // B
     buf.close()

@@ -7,7 +7,12 @@ import torch
 import ppo_amd
 from ppo_amd import _lib, synth
 cfg = sys.argv[1] if len(sys.argv) > 1 else "TGT"
-T, N, D, B = synth.CONFIGS[cfg]
+if "/" in cfg:                      # e.g. C5/8: the per-GPU shard of an 8-rank job
+    base, div = cfg.split("/")
+    T, N, D, B = synth.CONFIGS[base]
+    N, B = N // int(div), B // int(div)
+else:
+    T, N, D, B = synth.CONFIGS[cfg]
 M = T * N
 dev = torch.device("cuda", 0)
 buf = ppo_amd.ExperienceBuffer(N, D, T); buf.use_torch_stream()
