@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void scalar_gather_kernel(ScalarGatherArgs g) 
 // lines travel with the rows' stream instead of in a launch of their own: 839 us against 713 + 188 at TGT.
 // It only pays while the records (16 B x M) fit the Infinity Cache beside the stream; with 0.5 - 2 GB of
 // records (C3, C5 on one GPU) the random line fetches disturb the row stream and the split kernels win
-// (profiles/r2/ab_fused_*.log), so the host picks it by size.
+// (profiles/r2/ab_fused_shapes.log), so the host picks it by size.
 struct FusedGatherArgs {
   ObsGatherArgs o;
   ScalarGatherArgs s;
