@@ -2,6 +2,8 @@
 and wrapped rings), batch sizes (one row .. larger than the buffer), every GAE algorithm and scan
 shape, both gather block sizes, the split and the fused gather, library-drawn / caller-supplied permutations.  Every case goes through
 tests/test_gpu_parity.check_pass, i.e. the same bit-exact / stated-tolerance bars."""
+import os
+
 import numpy as np
 import pytest
 
@@ -30,7 +32,7 @@ def _case(g):
 @pytest.mark.parametrize("chunk", range(16))
 def test_random_configurations(xp, oracle, chunk):
     import ppo_amd
-    g = np.random.default_rng(0xF00D + chunk)
+    g = np.random.default_rng(0xF00D + chunk + 1000 * int(os.environ.get("PPO_XP_FUZZ_BASE", "0")))   # other bases: extra sweeps by hand
     for i in range(25):
         cap, steps, N, D, B = _case(g)
         algo_kind = int(g.integers(0, 3))
