@@ -187,6 +187,8 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     for t in tunables:
         k, v = t.split("=")
         buf.set_tunable(k, int(v))
+    if args.streaming and not ctx.multi:
+        buf.set_streaming(True)
     L, h = _lib.load(), buf.handle
 
     # ---- synthetic rollout, drawn on the device and inserted row by row (not timed) ----------
@@ -341,7 +343,8 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         "scaling": "strong" if cfg == "C5" else "weak",
         "config": {"workload": workload, "global_envs": world * N,
                    "parallelism": f"env-sharded x{world}" if ctx.multi else "single GPU",
-                   "exchange": ((args.exchange + "/" + args.backend) if ctx.multi else "none")},
+                   "exchange": ((args.exchange + "/" + args.backend) if ctx.multi else "none"),
+                   "minibatches": "streamed one at a time into two slots" if buf.streaming else "all K gathered by one pass launch"},
         "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
         "alg_bytes_per_transition": step_bytes,
         "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "fused_gather_kernel" if fused else "obs_gather_kernel",
@@ -370,6 +373,8 @@ def main():
     ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank control flow with all ranks on one GPU")
     ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
+    ap.add_argument("--streaming", action="store_true", help="gather minibatches one at a time into two slots (ppo_xp_set_streaming): "
+                                                              "half the memory of a pass; not with --gpus > 1")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 

@@ -209,7 +209,10 @@ int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_
  * sequence rand's shuffle would give for this seed; reproducible, with a CPU twin in the oracle. */
 int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed);
 /* Iterator::next (data.rs:115-192): 0 = *out filled, 1 = exhausted (`None`), < 0 error.
- * The windows follow data.rs:121-126 exactly, including the overlapping tail batch. */
+ * The windows follow data.rs:121-126 exactly, including the overlapping tail batch.
+ * Whole-pass mode (default): ppo_xp_pass_begin* gathered every minibatch, this only hands out slices of the slabs.
+ * Streaming mode (ppo_xp_set_streaming): THIS call enqueues the gather of minibatch k into one of two alternating
+ * B-row slots; the view stays valid until the call after the next one. */
 int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out);
 /* Iterator::next (data.rs:115-192) as the reference's caller sees it: the six arrays of minibatch k in
  * HOST memory (what data.rs:166-182 feeds to copy_from), so a Rust shim can keep returning
@@ -226,6 +229,14 @@ int ppo_xp_shuffle_prefetch(ppo_xp *h, uint64_t seed);
  * (rows and scalar streams in one launch; chosen by size, see the "fused" tunable), -1 = no pass.  For
  * measurement harnesses that attribute bytes to kernels. */
 int ppo_xp_pass_gather_kind(const ppo_xp *h);
+/* Streaming mode: a pass keeps two B-row minibatch slots instead of the K*B-row slabs (which are a second copy of
+ * the observations: 34 GB at T=2048, N=16384, D=256) and gathers minibatch k when ppo_xp_pass_next asks for it, so
+ * a consumer can work on minibatch k while k+1 is gathered (the double-buffered ownership of SURVEY.md 8(b)).  Same
+ * kernels, same bits as the whole-pass mode; K launches sets instead of one, so a pass takes a few percent longer.
+ * Not together with a statistics exchange (the single all-reduce per pass needs every minibatch's sums at once):
+ * PPO_XP_ESTATE.  Switching drops the slabs (synchronises) and ends the current pass.  A permutation borrowed by
+ * ppo_xp_pass_begin_device must then stay valid until the pass is exhausted.  No counterpart in the reference. */
+int ppo_xp_set_streaming(ppo_xp *h, int on);
 /* Number of minibatches of the current pass (ExperienceBatcher::len()/B rounded up). */
 size_t ppo_xp_pass_num_batches(const ppo_xp *h);
 /* The permutation of the current pass on the device (u32[M]) / copied to the host. */

@@ -80,6 +80,7 @@ SYMBOLS = {
     "ppo_xp_pass_next_host": (_i, [_vp, C.POINTER(BatchHost)]),
     "ppo_xp_shuffle_prefetch": (_i, [_vp, _u64]),
     "ppo_xp_pass_gather_kind": (_i, [_vp]),
+    "ppo_xp_set_streaming": (_i, [_vp, _i]),
     "ppo_xp_pass_num_batches": (_sz, [_vp]),
     "ppo_xp_pass_perm_device": (_vp, [_vp]),
     "ppo_xp_pass_perm_host": (_i, [_vp, _vp, _sz]),

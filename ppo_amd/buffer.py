@@ -94,6 +94,7 @@ class ExperienceBuffer:
         check(L.ppo_xp_create(C.byref(self._h), self.device, self.capacity, self.num_envs, self.obs_size,
                               self.gamma, self.lam))
         self._L = L
+        self.streaming = False
 
     # -- constructors with the reference's names ------------------------------------------
     @classmethod
@@ -286,6 +287,12 @@ class ExperienceBuffer:
     def set_exchange(self, mode: int, comm=None):
         """0 none, 1 library calls ncclAllReduce on `comm`, 2 caller all-reduces pass_sums()."""
         check(self._L.ppo_xp_set_exchange(self._h, int(mode), C.c_void_p(comm) if comm else None))
+
+    def set_streaming(self, on: bool = True):
+        """Gather minibatches one at a time into two alternating slots (half the memory of a pass, a few percent
+        slower) instead of all K at once; a batch handed out by the iterator is overwritten by the batch after next."""
+        check(self._L.ppo_xp_set_streaming(self._h, 1 if on else 0))
+        self.streaming = bool(on)
 
     def pass_sums(self, K):
         """Device view [K, 3] f64 of this rank's (count, sum, sum of squares) per minibatch."""

@@ -39,7 +39,8 @@ struct ObsGatherArgs {
   const float *obs;        // [M, D]
   const uint32_t *perm;    // [M]
   float *obs_out;          // [K*B, D]
-  size_t M, B, total;      // total = K*B*Q vector elements to move
+  size_t M, B, total;      // total = Kn*B*Q vector elements to move (Kn minibatches in this launch)
+  size_t row_base;         // first output row of the launch in the pass (k0*B; 0 unless minibatches are streamed one by one)
   unsigned Q, qshift;      // Q = D / V vector elements per row; qshift = log2(Q) when POW2
   unsigned nblocks, xcd;   // grid size; xcd: 0 = identity, 1 = 8x8 chunk remap, 2 = one contiguous eighth per XCD
 };
@@ -73,10 +74,10 @@ __device__ __forceinline__ void obs_gather_body(const ObsGatherArgs &g, size_t b
   size_t row; unsigned col;                                   // output row (k*B + r), vector column
   if (POW2) { row = e >> g.qshift; col = (unsigned)e & (g.Q - 1); }
   else { row = e / g.Q; col = (unsigned)(e - row * g.Q); }
-  size_t pos = row;                                           // position in the permutation
+  size_t pos = g.row_base + row;                              // position in the permutation
   if (TAIL) {                                                 // data.rs:121-122
-    const size_t k = row / g.B, start = k * g.B;
-    if (start + g.B > g.M) pos = row - start + (g.M - g.B);
+    const size_t k = pos / g.B, start = k * g.B;
+    if (start + g.B > g.M) pos = pos - start + (g.M - g.B);
   }
   uint32_t p = g.perm[pos];
   p = min(p, (uint32_t)(g.M - 1));                            // a bad index can never fault
@@ -100,6 +101,7 @@ struct ScalarGatherArgs {
   double2 *partials;       // [K * tiles_per_mb] (sum, sum of squares) per 256-row tile
   size_t M, B;
   unsigned tiles_per_mb;   // ceil(B / rows per tile); a tile = the rows of one workgroup = one (sum, sumsq) partial
+  unsigned k0;             // first minibatch of the launch (0 unless minibatches are streamed one by one)
   int rec_nt, out_nt;      // cache policy of the record reads / of the output stores
 };
 
@@ -119,7 +121,7 @@ __device__ __forceinline__ void scalar_gather_body(const ScalarGatherArgs &g, un
   const unsigned c = tile - k * g.tiles_per_mb;
   const unsigned w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
   const size_t r = (size_t)c * BS + threadIdx.x;              // row inside minibatch k
-  size_t start = (size_t)k * g.B;
+  size_t start = (size_t)(g.k0 + k) * g.B;
   if (start + g.B > g.M) start = g.M - g.B;                   // data.rs:121-122
   const bool valid = r < g.B;
   float adv = 0.f;
@@ -194,10 +196,10 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
     const size_t row = row0 + (threadIdx.x >> g.o.qshift);
     const unsigned col = threadIdx.x & (Q - 1);
     if (row < KB) {
-      size_t pos = row;
+      size_t pos = g.o.row_base + row;
       if (TAIL) {
-        const size_t k = row / g.o.B, start = k * g.o.B;
-        if (start + g.o.B > g.o.M) pos = row - start + (g.o.M - g.o.B);
+        const size_t k = pos / g.o.B, start = k * g.o.B;
+        if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
       }
       uint32_t p = g.o.perm[pos];
       p = min(p, (uint32_t)(g.o.M - 1));
@@ -213,10 +215,10 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
     const bool valid = threadIdx.x < rpw && row < KB;
     float adv = 0.f;
     if (valid) {
-      size_t pos = row;
+      size_t pos = g.o.row_base + row;
       if (TAIL) {
-        const size_t k = row / g.o.B, start = k * g.o.B;
-        if (start + g.o.B > g.o.M) pos = row - start + (g.o.M - g.o.B);
+        const size_t k = pos / g.o.B, start = k * g.o.B;
+        if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
       }
       uint32_t p = g.s.perm[pos];
       p = min(p, (uint32_t)(g.s.M - 1));

@@ -159,6 +159,8 @@ struct ppo_xp {
   size_t pass_B = 0, pass_K = 0, pass_M = 0, pass_iter = 0;
   bool pass_active = false, pass_pending_finish = false;
   int pass_kind = 0;         // 0: scalar_gather_kernel + obs_gather_kernel, 1: fused_gather_kernel
+  bool streaming = false;    // minibatches are gathered one at a time by pass_next into two alternating B-row slabs
+  bool pass_streamed = false, pass_fusable = false;   // how the current pass was begun
   std::vector<uint32_t> perm_host;
   // Fisher-Yates of a coming pass drawn by a background thread (ppo_xp_shuffle_prefetch)
   std::thread pf_thread; std::vector<uint32_t> pf_perm; uint64_t pf_seed = 0; size_t pf_M = 0; bool pf_valid = false;
@@ -381,13 +383,14 @@ void launch_obs_v(ppo_xp *h, const ObsGatherArgs &g, unsigned blocks, bool pow2,
   }
 }
 
-int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M) {
+// Kn minibatches starting with minibatch k0, written to obs_out (rows [0, Kn*B) of it).
+int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M, size_t k0, size_t Kn, float *obs_out) {
   const unsigned D = (unsigned)h->D;
   const int V = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
   ObsGatherArgs g{};
-  g.obs = h->obs; g.perm = h->perm_cur; g.obs_out = h->obs_out; g.M = M; g.B = B;
+  g.obs = h->obs; g.perm = h->perm_cur; g.obs_out = obs_out; g.M = M; g.B = B; g.row_base = k0 * B;
   g.Q = D / V;
-  g.total = K * B * g.Q;
+  g.total = Kn * B * g.Q;
   const bool pow2 = (g.Q & (g.Q - 1)) == 0;
   g.qshift = 0;
   if (pow2) while ((1u << g.qshift) < g.Q) ++g.qshift;
@@ -457,7 +460,8 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   // one over the full ring does not move the slabs (views of the earlier pass stay valid memory);
   // a larger batch size later still re-allocates: views die with the next pass_begin (include/ppo_xp.h)
   const size_t Mcap = h->capacity * h->N;
-  const size_t rows = std::max(K * B, B <= Mcap ? ((Mcap + B - 1) / B) * B : (size_t)0);
+  // streaming: two alternating B-row slots instead of the K*B-row slab (no second copy of the observations)
+  const size_t rows = h->streaming ? 2 * B : std::max(K * B, B <= Mcap ? ((Mcap + B - 1) / B) * B : (size_t)0);
   if (rows > h->slab_rows) {
     HIP_TRY(hipStreamSynchronize(h->stream));   // kernels of the previous pass may still write the old slabs
     dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out);
@@ -487,25 +491,143 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   return 0;
 }
 
-// fold = true: no finalize_stats launch preceded; the normalize workgroups reduce the partials themselves.
-int pass_finish_impl(ppo_xp *h, bool fold = false, unsigned fold_stat_tiles = 0, const double2 *fold_partials = nullptr) {
-  const size_t K = h->pass_K, B = h->pass_B;
-  if (K == 0) { h->pass_pending_finish = false; return 0; }
+// Where a launch range puts its results: the slabs of the whole pass, or (streaming) one of the two B-row slots.
+struct PassOut {
+  float *obs, *val, *nlp, *ret, *adv;
+  int64_t *act;
+  double *sums;    // [Kn][3]
+  float *stats;    // [Kn][2]
+};
+
+PassOut pass_out_at(const ppo_xp *h, size_t row, size_t k) {
+  PassOut o;
+  o.obs = h->obs_out + row * h->D; o.val = h->val_out + row; o.nlp = h->nlp_out + row; o.ret = h->ret_out + row;
+  o.adv = h->adv_out + row; o.act = h->act_out + row; o.sums = h->sums + 3 * k; o.stats = h->stats + 2 * k;
+  return o;
+}
+
+// Standardises Kn minibatches in place.  fold = true: no finalize_stats launch preceded; the normalize workgroups
+// reduce the partials themselves.
+int normalize_range(ppo_xp *h, size_t Kn, const PassOut &o, bool fold = false, unsigned fold_stat_tiles = 0,
+                    const double2 *fold_partials = nullptr) {
+  const size_t B = h->pass_B;
+  if (Kn == 0) return 0;
   const unsigned vpt = (fold && B >= 65536) ? 4u : 1u;      // the fold is paid per workgroup: fewer, fatter ones for big minibatches
   const size_t nbx = (B + 1024 * vpt - 1) / (1024 * vpt);
-  if (K * nbx > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for the normalize launch");
+  if (Kn * nbx > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for the normalize launch");
   const unsigned stat_tiles = fold_stat_tiles ? fold_stat_tiles : (unsigned)((B + 255) / 256);
   ProfScope ps(h, PPO_XP_K_NORMALIZE);
   const double2 *fp = fold_partials ? fold_partials : h->partials;
-  const dim3 grid((unsigned)(K * nbx));
+  const dim3 grid((unsigned)(Kn * nbx));
   if (fold && vpt == 4)
-    hipLaunchKernelGGL((normalize_kernel<true, 4>), grid, dim3(256), 0, h->stream, h->adv_out, h->sums, fp, stat_tiles, h->stats, B, (unsigned)nbx);
+    hipLaunchKernelGGL((normalize_kernel<true, 4>), grid, dim3(256), 0, h->stream, o.adv, o.sums, fp, stat_tiles, o.stats, B, (unsigned)nbx);
   else if (fold)
-    hipLaunchKernelGGL((normalize_kernel<true, 1>), grid, dim3(256), 0, h->stream, h->adv_out, h->sums, fp, stat_tiles, h->stats, B, (unsigned)nbx);
+    hipLaunchKernelGGL((normalize_kernel<true, 1>), grid, dim3(256), 0, h->stream, o.adv, o.sums, fp, stat_tiles, o.stats, B, (unsigned)nbx);
   else
-    hipLaunchKernelGGL((normalize_kernel<false, 1>), grid, dim3(256), 0, h->stream, h->adv_out, h->sums, fp, stat_tiles, h->stats, B, (unsigned)nbx);
-  h->pass_pending_finish = false;
+    hipLaunchKernelGGL((normalize_kernel<false, 1>), grid, dim3(256), 0, h->stream, o.adv, o.sums, fp, stat_tiles, o.stats, B, (unsigned)nbx);
   return launch_check("normalize_kernel");
+}
+
+// ppo_xp_pass_finish and the tail of a sharded pass: the whole pass, statistics already in h->sums.
+int pass_finish_impl(ppo_xp *h) {
+  h->pass_pending_finish = false;
+  return normalize_range(h, h->pass_K, pass_out_at(h, 0, 0));
+}
+
+// Gathers and standardises minibatches [k0, k0 + Kn) of the current pass into `o`.  Whole pass: k0 = 0, Kn = K;
+// streaming: one minibatch at a time.  Exchange modes (sharded ranks) only occur with the whole pass.
+int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
+  const size_t K = h->pass_K, B = h->pass_B, M = h->pass_M;
+  const bool whole = k0 == 0 && Kn == K;
+  const unsigned Dq = (unsigned)h->D / 4;
+  const unsigned FBq = (unsigned)h->fused_block;
+  const unsigned rpw = (Dq && FBq % Dq == 0) ? FBq / Dq : 0u;
+  if (h->pass_fusable) {
+    FusedGatherArgs f{};
+    f.rpw = rpw;
+    f.o.obs = h->obs; f.o.perm = h->perm_cur; f.o.obs_out = o.obs; f.o.M = M; f.o.B = B; f.o.Q = Dq; f.o.row_base = k0 * B;
+    f.o.total = Kn * B * Dq; f.o.qshift = 0;
+    while ((1u << f.o.qshift) < Dq) ++f.o.qshift;
+    f.s.rec = h->rec; f.s.actions = h->actions; f.s.perm = h->perm_cur; f.s.act_out = o.act;
+    f.s.val_out = o.val; f.s.nlp_out = o.nlp; f.s.ret_out = o.ret; f.s.adv_out = o.adv;
+    f.s.partials = h->partials; f.s.M = M; f.s.B = B; f.s.tiles_per_mb = (unsigned)(B / rpw); f.s.k0 = (unsigned)k0;
+    const size_t blocks = Kn * (B / rpw);
+    if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
+    {
+      ProfScope ps(h, PPO_XP_K_GATHER);
+      const bool tail = K * B != M;
+      const dim3 grid((unsigned)blocks);
+      if (FBq == 256) {
+        if (tail) hipLaunchKernelGGL((fused_gather_kernel<256, true, true>), grid, dim3(256), 0, h->stream, f);
+        else hipLaunchKernelGGL((fused_gather_kernel<256, true, false>), grid, dim3(256), 0, h->stream, f);
+      } else {
+        if (tail) hipLaunchKernelGGL((fused_gather_kernel<512, true, true>), grid, dim3(512), 0, h->stream, f);
+        else hipLaunchKernelGGL((fused_gather_kernel<512, true, false>), grid, dim3(512), 0, h->stream, f);
+      }
+      if (int rc = launch_check("fused_gather_kernel")) return rc;
+    }
+    // statistics: few tiles per minibatch -> every standardise workgroup folds them itself; many -> one
+    // launch folds groups of 256 first (fixed order either way: deterministic)
+    const unsigned tiles = f.s.tiles_per_mb;
+    if (h->xmode == 0 && tiles <= 1024u) return normalize_range(h, Kn, o, true, tiles);
+    const unsigned G = (tiles + 255u) / 256u;
+    double2 *partials2 = h->partials + Kn * (size_t)tiles;
+    const bool two_level = tiles > 1024u;
+    if (two_level) {
+      ProfScope ps(h, PPO_XP_K_FINALIZE);
+      hipLaunchKernelGGL(reduce_partials_kernel, dim3(G, (unsigned)Kn), dim3(256), 0, h->stream, h->partials, partials2, tiles);
+      if (int rc = launch_check("reduce_partials_kernel")) return rc;
+    }
+    if (h->xmode == 0) return normalize_range(h, Kn, o, true, G, partials2);
+    // sharded: this rank's (count, sum, sumsq) per minibatch must exist as numbers, they cross the ranks
+    {
+      ProfScope ps(h, PPO_XP_K_FINALIZE);
+      hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)Kn), dim3(256), 0, h->stream, two_level ? partials2 : h->partials,
+                         o.sums, two_level ? G : tiles, B);
+      if (int rc = launch_check("finalize_stats_kernel")) return rc;
+    }
+    if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
+    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+    return pass_finish_impl(h);
+  }
+  // scalar streams + statistics first (the records were just written by the GAE kernel and are
+  // the most likely bytes to still sit in the Infinity Cache), observation rows after
+  ScalarGatherArgs g{};
+  g.rec = h->rec; g.actions = h->actions; g.perm = h->perm_cur; g.act_out = o.act;
+  g.val_out = o.val; g.nlp_out = o.nlp; g.ret_out = o.ret; g.adv_out = o.adv;
+  g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256); g.k0 = (unsigned)k0;
+  g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
+  const bool partitioned = whole && h->scalar_path == 1 && K * B == M && M >= kPartChunk &&
+                           ((M + (size_t(1) << kSrcShift) - 1) >> kSrcShift) <= kMaxBins && ((M + (size_t(1) << kDstShift) - 1) >> kDstShift) <= kMaxBins;
+  if (partitioned) {
+    if (int rc = launch_partitioned_scalars(h, g, K, B, M)) return rc;
+  } else {
+    ProfScope ps(h, PPO_XP_K_SCALARS);
+    hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(Kn * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
+    if (int rc = launch_check("scalar_gather_kernel")) return rc;
+  }
+  // single GPU and few tiles per minibatch (C2: 64): the normalize workgroups fold the partials
+  // themselves and the finalize launch (4.5 us, a tenth of such a pass) is skipped
+  const bool fold = h->xmode == 0 && g.tiles_per_mb <= (unsigned)h->fold_tiles;
+  if (!fold) {
+    ProfScope ps(h, PPO_XP_K_FINALIZE);
+    hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)Kn), dim3(256), 0, h->stream, h->partials, o.sums,
+                       g.tiles_per_mb, B);
+    if (int rc = launch_check("finalize_stats_kernel")) return rc;
+  }
+  if (h->xmode == 0) {
+    // single GPU: standardise while the raw advantages are still in L2 / Infinity Cache, rows last
+    if (int rc = normalize_range(h, Kn, o, fold)) return rc;
+    return launch_obs_gather(h, K, B, M, k0, Kn, o.obs);
+  }
+  // sharded: the observation rows do not depend on the statistics; enqueue them before the
+  // exchange so that the all-reduce's host-side latency hides behind ~0.7 ms of GPU work
+  if (int rc = launch_obs_gather(h, K, B, M, k0, Kn, o.obs)) return rc;
+  if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
+  int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+  return pass_finish_impl(h);
 }
 
 // perm already in h->perm_cur (device).
@@ -515,11 +637,12 @@ int pass_begin_body(ppo_xp *h, size_t B) {
     return fail(PPO_XP_ESTATE, "pass_begin: call ppo_xp_returns() first (ExperienceBatcher::new takes the returns, data.rs:27)");
   h->pass_B = B; h->pass_M = M; h->pass_iter = 0; h->pass_active = true; h->pass_pending_finish = false;
   h->pass_K = (B > M) ? 0 : (M + B - 1) / B;                 // data.rs:117-126
+  h->pass_streamed = h->streaming;
   const size_t K = h->pass_K;
   if (K == 0) return 0;
   if (K * ((B + 255) / 256) > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
   // rows per statistics tile (= per workgroup of whichever kernel gathers the scalar streams).
-  // The fused kernel (rows + scalar streams in one workgroup) is taken on one GPU when a workgroup covers 8..64
+  // The fused kernel (rows + scalar streams in one workgroup) is taken when a workgroup covers 8..64
   // whole rows and the records fit the Infinity Cache beside the row stream (measured: TGT 134 MB wins 75 us,
   // C3 0.5 GB and C5-on-one-GPU 2.1 GB lose); "fused" = 0 / 1 forces the choice, -1 decides by size.
   const unsigned Dq = (unsigned)h->D / 4;
@@ -538,92 +661,9 @@ int pass_begin_body(ppo_xp *h, size_t B) {
     h->have_rec = true;
   }
   h->pass_kind = fusable ? 1 : 0;
-  if (fusable) {
-    FusedGatherArgs f{};
-    f.rpw = rpw;
-    f.o.obs = h->obs; f.o.perm = h->perm_cur; f.o.obs_out = h->obs_out; f.o.M = M; f.o.B = B; f.o.Q = Dq;
-    f.o.total = K * B * Dq; f.o.qshift = 0;
-    while ((1u << f.o.qshift) < Dq) ++f.o.qshift;
-    f.s.rec = h->rec; f.s.actions = h->actions; f.s.perm = h->perm_cur; f.s.act_out = h->act_out;
-    f.s.val_out = h->val_out; f.s.nlp_out = h->nlp_out; f.s.ret_out = h->ret_out; f.s.adv_out = h->adv_out;
-    f.s.partials = h->partials; f.s.M = M; f.s.B = B; f.s.tiles_per_mb = (unsigned)(B / rpw);
-    const size_t blocks = K * (B / rpw);
-    if (blocks > 0x7fffffffull) return fail(PPO_XP_EINVAL, "pass too large for one launch");
-    {
-      ProfScope ps(h, PPO_XP_K_GATHER);
-      const bool tail = K * B != M;
-      const dim3 grid((unsigned)blocks);
-      if (FBq == 256) {
-        if (tail) hipLaunchKernelGGL((fused_gather_kernel<256, true, true>), grid, dim3(256), 0, h->stream, f);
-        else hipLaunchKernelGGL((fused_gather_kernel<256, true, false>), grid, dim3(256), 0, h->stream, f);
-      } else {
-        if (tail) hipLaunchKernelGGL((fused_gather_kernel<512, true, true>), grid, dim3(512), 0, h->stream, f);
-        else hipLaunchKernelGGL((fused_gather_kernel<512, true, false>), grid, dim3(512), 0, h->stream, f);
-      }
-      if (int rc = launch_check("fused_gather_kernel")) return rc;
-    }
-    // statistics: few tiles per minibatch -> every standardise workgroup folds them itself; many -> one
-    // launch folds groups of 256 first (fixed order either way: deterministic)
-    const unsigned tiles = f.s.tiles_per_mb;
-    if (h->xmode == 0 && tiles <= 1024u) return pass_finish_impl(h, true, tiles);
-    const unsigned G = (tiles + 255u) / 256u;
-    double2 *partials2 = h->partials + K * (size_t)tiles;
-    const bool two_level = tiles > 1024u;
-    if (two_level) {
-      ProfScope ps(h, PPO_XP_K_FINALIZE);
-      hipLaunchKernelGGL(reduce_partials_kernel, dim3(G, (unsigned)K), dim3(256), 0, h->stream, h->partials, partials2, tiles);
-      if (int rc = launch_check("reduce_partials_kernel")) return rc;
-    }
-    if (h->xmode == 0) return pass_finish_impl(h, true, G, partials2);
-    // sharded: this rank's (count, sum, sumsq) per minibatch must exist as numbers, they cross the ranks
-    {
-      ProfScope ps(h, PPO_XP_K_FINALIZE);
-      hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, two_level ? partials2 : h->partials,
-                         h->sums, two_level ? G : tiles, B);
-      if (int rc = launch_check("finalize_stats_kernel")) return rc;
-    }
-    if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
-    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
-    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
-    return pass_finish_impl(h);
-  }
-  // scalar streams + statistics first (the records were just written by the GAE kernel and are
-  // the most likely bytes to still sit in the Infinity Cache), observation rows after
-  ScalarGatherArgs g{};
-  g.rec = h->rec; g.actions = h->actions; g.perm = h->perm_cur; g.act_out = h->act_out;
-  g.val_out = h->val_out; g.nlp_out = h->nlp_out; g.ret_out = h->ret_out; g.adv_out = h->adv_out;
-  g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256);
-  g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
-  const bool partitioned = h->scalar_path == 1 && K * B == M && M >= kPartChunk &&
-                           ((M + (size_t(1) << kSrcShift) - 1) >> kSrcShift) <= kMaxBins && ((M + (size_t(1) << kDstShift) - 1) >> kDstShift) <= kMaxBins;
-  if (partitioned) {
-    if (int rc = launch_partitioned_scalars(h, g, K, B, M)) return rc;
-  } else {
-    ProfScope ps(h, PPO_XP_K_SCALARS);
-    hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(K * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
-    if (int rc = launch_check("scalar_gather_kernel")) return rc;
-  }
-  // single GPU and few tiles per minibatch (C2: 64): the normalize workgroups fold the partials
-  // themselves and the finalize launch (4.5 us, a tenth of such a pass) is skipped
-  const bool fold = h->xmode == 0 && g.tiles_per_mb <= (unsigned)h->fold_tiles;
-  if (!fold) {
-    ProfScope ps(h, PPO_XP_K_FINALIZE);
-    hipLaunchKernelGGL(finalize_stats_kernel, dim3((unsigned)K), dim3(256), 0, h->stream, h->partials, h->sums,
-                       g.tiles_per_mb, B);
-    if (int rc = launch_check("finalize_stats_kernel")) return rc;
-  }
-  if (h->xmode == 0) {
-    // single GPU: standardise while the raw advantages are still in L2 / Infinity Cache, rows last
-    if (int rc = pass_finish_impl(h, fold)) return rc;
-    return launch_obs_gather(h, K, B, M);
-  }
-  // sharded: the observation rows do not depend on the statistics; enqueue them before the
-  // exchange so that the all-reduce's host-side latency hides behind ~0.7 ms of GPU work
-  if (int rc = launch_obs_gather(h, K, B, M)) return rc;
-  if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
-  int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
-  if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
-  return pass_finish_impl(h);
+  h->pass_fusable = fusable;
+  if (h->pass_streamed) return 0;            // ppo_xp_pass_next gathers minibatch k when it is asked for
+  return gather_range(h, 0, K, pass_out_at(h, 0, 0));
 }
 
 // A pass that failed half-way (allocation, launch, all-reduce) must not hand out minibatches.
@@ -996,14 +1036,21 @@ int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out) {
   const size_t B = h->pass_B, M = h->pass_M;
   if (B > M || h->pass_iter >= M) return 1;                      // data.rs:117-119 -> None
   const size_t k = h->pass_iter / B;
+  // whole-pass mode: minibatch k is rows [k*B, (k+1)*B) of the slabs, gathered by pass_begin.  Streaming: it is
+  // gathered NOW into slot k % 2 (the view handed out two calls ago is overwritten)
+  const size_t row = h->pass_streamed ? (k & 1) * B : k * B;
+  if (h->pass_streamed) {
+    HIP_TRY(hipSetDevice(h->device));
+    if (int rc = gather_range(h, k, 1, pass_out_at(h, row, k))) return rc;
+  }
   h->pass_iter += B;                                             // data.rs:126
   out->index = k; out->batch_size = B; out->obs_size = h->D;
-  out->observations = h->obs_out + k * B * h->D;
-  out->actions = h->act_out + k * B;
-  out->values = h->val_out + k * B;
-  out->neglogps = h->nlp_out + k * B;
-  out->returns = h->ret_out + k * B;
-  out->advantages = h->adv_out + k * B;
+  out->observations = h->obs_out + row * h->D;
+  out->actions = h->act_out + row;
+  out->values = h->val_out + row;
+  out->neglogps = h->nlp_out + row;
+  out->returns = h->ret_out + row;
+  out->advantages = h->adv_out + row;
   out->adv_mean = 0.f; out->adv_std = 0.f;
   return 0;
 }
@@ -1076,9 +1123,25 @@ int ppo_xp_pass_stats_host(ppo_xp *h, float *mean_std_out, size_t k) {
   return 0;
 }
 
+int ppo_xp_set_streaming(ppo_xp *h, int on) {
+  if (!h) return fail(PPO_XP_EINVAL, "set_streaming: handle is NULL");
+  if (on && h->xmode != 0) return fail(PPO_XP_ESTATE, "set_streaming: not with a statistics exchange (one all-reduce per pass needs the whole pass)");
+  if ((on != 0) != h->streaming) {
+    // the slabs change size: drop them (after the stream has finished with them); the next pass re-allocates
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out); dev_free(h->adv_out);
+    h->slab_rows = 0;
+    h->pass_active = false;
+  }
+  h->streaming = on != 0;
+  return 0;
+}
+
 int ppo_xp_set_exchange(ppo_xp *h, int mode, void *nccl_comm) {
   if (!h) return fail(PPO_XP_EINVAL, "set_exchange: handle is NULL");
   if (mode < 0 || mode > 2) return fail(PPO_XP_EINVAL, "set_exchange: mode %d", mode);
+  if (mode != 0 && h->streaming) return fail(PPO_XP_ESTATE, "set_exchange: not while minibatches are streamed (ppo_xp_set_streaming)");
   if (mode == 1) {
     if (!nccl_comm) return fail(PPO_XP_EINVAL, "set_exchange: mode 1 needs a ncclComm_t");
     if (int rc = rccl_load()) return rc;

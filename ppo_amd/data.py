@@ -168,7 +168,7 @@ class ExperienceBatcherIterator:
         rc = check(self.batcher._L.ppo_xp_pass_next(buf.handle, C.byref(v)))
         if rc == 1:
             raise StopIteration
-        if v.index == 0:
+        if v.index == 0 or buf.streaming:      # streaming: this very call enqueued the minibatch's kernels
             buf.sync()
         B, D, d = v.batch_size, v.obs_size, buf.device
         f32, i64 = torch.float32, torch.int64

@@ -264,3 +264,55 @@ def test_partitioned_scalar_path_matches_the_direct_gather(xp, oracle, T, N, D, 
     np.testing.assert_array_equal(outs[1][0][1].astype(np.uint64), oracle.gather_u64(act_o, perm))
     np.testing.assert_array_equal(bits(outs[1][0][2]), bits(oracle.gather_f32(val_o, perm)))
     g.close()
+
+
+@pytest.mark.parametrize("T,N,D,B,fused", [(16, 128, 64, 512, 1),      # fused gather, B divides M
+                                           (9, 130, 64, 320, -1),      # fused gather with an overlapping tail window
+                                           (12, 100, 6, 77, 0),        # split kernels, tail, odd row width
+                                           (5, 64, 8, 320, 0)])        # one minibatch
+def test_streaming_mode_matches_the_whole_pass(xp, oracle, T, N, D, B, fused):
+    """ppo_xp_set_streaming: minibatch k is gathered by pass_next into one of two B-row slots.  Same kernels on a
+    range of rows: every minibatch must hold the bits of the whole-pass mode, the slots must alternate, and the
+    host hand-off, the statistics and the switch back must work."""
+    import torch
+    from ppo_amd import _lib
+    g, o, r = _both(xp, oracle, T, N, D, 5 + T, big_actions=True)
+    g.set_tunable("fused", fused)
+    g.returns(r["last_dones"])
+    M = T * N
+    fields = ("observations", "actions", "values", "neglogps", "returns", "advantages")
+    it = xp.ExperienceBatcher(g, B).into_iter(seed=9)
+    whole = [[getattr(b, f).clone() for f in fields] for b in it]
+    stats_whole = it.stats()
+    g.set_streaming(True)
+    it = xp.ExperienceBatcher(g, B).into_iter(seed=9)
+    np.testing.assert_array_equal(it.perm(), oracle.shuffle(9, M))
+    ptrs, n = [], 0
+    for k, b in enumerate(it):
+        ptrs.append(b.observations.data_ptr())
+        for f, want in zip(fields, whole[k]):
+            got = getattr(b, f)
+            assert torch.equal(got.view(torch.int32) if got.dtype == torch.float32 else got,
+                               want.view(torch.int32) if want.dtype == torch.float32 else want), (k, f)
+        n += 1
+    assert n == len(whole) == oracle.num_batches(M, B)
+    assert all(ptrs[i] == ptrs[i % 2] for i in range(n)) and (n < 2 or ptrs[0] != ptrs[1])   # two alternating slots
+    np.testing.assert_array_equal(bits(it.stats()), bits(stats_whole))
+    # the host hand-off on top of the streamed pass
+    it = xp.ExperienceBatcher(g, B).into_iter(seed=9)
+    hb = xp.HostBatch.pageable(B, D)
+    for k in range(n):
+        b = it.next_host(hb)
+        np.testing.assert_array_equal(bits(b.advantages), bits(whole[k][5].cpu().numpy()))
+        np.testing.assert_array_equal(bits(b.observations), bits(whole[k][0].cpu().numpy()))
+    assert it.next_host(hb) is None
+    # an exchange cannot be combined with streaming, and switching back restores the whole-pass slabs
+    with pytest.raises(xp.PpoXpError):
+        g.set_exchange(2)
+    g.set_streaming(False)
+    again = [[getattr(b, f).clone() for f in fields] for b in xp.ExperienceBatcher(g, B).into_iter(seed=9)]
+    assert all(torch.equal(a[5].view(torch.int32), w[5].view(torch.int32)) for a, w in zip(again, whole))
+    g.set_exchange(2)
+    with pytest.raises(xp.PpoXpError):
+        g.set_streaming(True)
+    g.close()
