@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <numeric>
 #include <random>
@@ -193,6 +194,72 @@ int main() {
   check_pass(h, 160, M / 160);
   REQUIRE(ppo_xp_set_exchange(h, 1, nullptr) == PPO_XP_EINVAL);
   REQUIRE(ppo_xp_attach_comm(h, nullptr, 0, 1) == 0);                        // detaches: mode 0
+
+  // ---- round 2 entry points: allocation-free returns, worker-thread shuffle, host minibatches, streaming ---
+  {
+    std::vector<float> ra(cap * N), rb(cap * N);
+    const int assoc = PPO_XP_GAE_ASSOC | PPO_XP_GAE_CHUNK(3);
+    REQUIRE(ppo_xp_returns(h, r.last_dones.data(), N, assoc, ra.data()) == 0);
+    REQUIRE(ppo_xp_returns_noalloc(h, r.last_dones.data(), N, assoc, rb.data()) == 0);
+    REQUIRE(std::memcmp(ra.data(), rb.data(), ra.size() * sizeof(float)) == 0);
+    REQUIRE(ppo_xp_returns_noalloc(h, r.last_dones.data(), N + 1, assoc, rb.data()) == PPO_XP_EINVAL);
+    REQUIRE(ppo_xp_returns(h, r.last_dones.data(), N, 0, nullptr) == 0);
+    REQUIRE(ppo_xp_pass_gather_kind(h) == -1);                                // no pass yet
+    REQUIRE(ppo_xp_shuffle_prefetch(h, 77) == 0);
+    REQUIRE(ppo_xp_pass_begin(h, 224, nullptr, 77) == 0);                     // takes the prefetched permutation
+    REQUIRE(ppo_xp_pass_gather_kind(h) == 0);                                 // D = 12: the split kernels
+    std::vector<uint32_t> p1(M), p2(M);
+    REQUIRE(ppo_xp_pass_perm_host(h, p1.data(), M) == 0);
+    ppo_xp_views_t vw;
+    REQUIRE(ppo_xp_views(h, &vw) == 0 && vw.num_steps == M);
+    std::vector<float> store_obs(M * D), store_val(M);
+    std::vector<int64_t> store_act(M);
+    REQUIRE(ppo_xp_sync(h) == 0);
+    REQUIRE(hipMemcpy(store_obs.data(), vw.observations, M * D * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+    REQUIRE(hipMemcpy(store_val.data(), vw.values, M * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+    REQUIRE(hipMemcpy(store_act.data(), vw.actions, M * sizeof(int64_t), hipMemcpyDeviceToHost) == hipSuccess);
+    std::vector<float> hobs(224 * D), hv(224), hn(224), hr(224), ha(224), adv_whole;
+    std::vector<size_t> hact(224);
+    ppo_batch_host io{};
+    io.capacity = 224; io.observations = hobs.data(); io.actions = hact.data(); io.values = hv.data();
+    io.neglogps = hn.data(); io.returns = hr.data(); io.advantages = ha.data();
+    size_t nb = 0;
+    while (true) {
+      const int rc = ppo_xp_pass_next_host(h, &io);
+      REQUIRE(rc == 0 || rc == 1);
+      if (rc == 1) break;
+      REQUIRE(io.index == nb && io.batch_size == 224 && io.obs_size == D);
+      const size_t start = std::min(nb * 224, M - 224);                       // data.rs:121-125
+      for (size_t j = 0; j < 224; ++j) {                                     // rows = storage[perm[...]], bit for bit
+        const uint32_t src = p1[start + j];
+        REQUIRE(std::memcmp(&hobs[j * D], &store_obs[src * D], D * sizeof(float)) == 0);
+        REQUIRE((int64_t)hact[j] == store_act[src] && hv[j] == store_val[src]);
+      }
+      adv_whole.insert(adv_whole.end(), ha.begin(), ha.end());
+      ++nb;
+    }
+    REQUIRE(nb == M / 224);
+    io.capacity = 10;
+    REQUIRE(ppo_xp_pass_begin(h, 224, nullptr, 77) == 0);                     // same seed, drawn on this thread now
+    REQUIRE(ppo_xp_pass_perm_host(h, p2.data(), M) == 0 && p1 == p2);
+    REQUIRE(ppo_xp_pass_next_host(h, &io) == PPO_XP_EINVAL);                  // destination too small: not consumed
+    io.capacity = 224;
+    REQUIRE(ppo_xp_pass_next_host(h, &io) == 0 && io.index == 0);
+    // streaming: two slots, same bits
+    REQUIRE(ppo_xp_set_streaming(h, 1) == 0);
+    REQUIRE(ppo_xp_set_exchange(h, 2, nullptr) == PPO_XP_ESTATE);
+    REQUIRE(ppo_xp_pass_begin(h, 224, nullptr, 77) == 0);
+    const float *slot[2] = {nullptr, nullptr};
+    for (size_t k = 0; k < nb; ++k) {
+      REQUIRE(ppo_xp_pass_next(h, &bv) == 0 && bv.index == k);
+      if (k < 2) slot[k] = bv.observations; else REQUIRE(bv.observations == slot[k & 1]);
+      REQUIRE(ppo_xp_sync(h) == 0);
+      REQUIRE(hipMemcpy(ha.data(), bv.advantages, 224 * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess);
+      REQUIRE(std::memcmp(ha.data(), &adv_whole[k * 224], 224 * sizeof(float)) == 0);
+    }
+    REQUIRE(ppo_xp_pass_next(h, &bv) == 1 && slot[0] != slot[1]);
+    REQUIRE(ppo_xp_set_streaming(h, 0) == 0);
+  }
 
   // ---- rows from page-locked host memory ------------------------------------------------------
   {
