@@ -141,6 +141,7 @@ struct ppo_xp {
   // is reused 8 calls later; one event per 4 calls (two alternate) tells when those scans have run.
   uint8_t *last_dones_pin = nullptr, *last_dones_pin_dev = nullptr;
   hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};
+  hipEvent_t perm_ev = nullptr; bool perm_ev_used = false;       // marks the end of the last upload from perm_host
   unsigned pin_next = 0;
   const uint8_t *last_dones_cur = nullptr;   // device address of the slot of the current call
   float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
@@ -734,6 +735,7 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
   if (!rc) h->own_stream = true;
   for (int i = 0; i < 2 && !rc; ++i)
     if (hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
+  if (!rc && hipEventCreateWithFlags(&h->perm_ev, hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(PPO_XP_EIO, "create: device sync failed");
   // set-up of the allocation-free entry point: this device's address of the static scratch
   if (!rc) { float *sp = nullptr; rc = scratch_for_device(device, &sp); }
@@ -750,6 +752,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
+  if (h->perm_ev) (void)hipEventDestroy(h->perm_ev);
   dev_free(h->obs); dev_free(h->rewards); dev_free(h->actions); dev_free(h->values); dev_free(h->dones);
   dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->done_bits); dev_free(h->perm);
   dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
@@ -928,8 +931,8 @@ int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64
   HIP_TRY(hipSetDevice(h->device));
   const size_t M = buf_len(h) * h->N;
   if (M) {
-    // previous upload may still be reading perm_host
-    HIP_TRY(hipStreamSynchronize(h->stream));
+    // the previous upload may still be reading perm_host; the rest of the stream need not drain
+    if (h->perm_ev_used) HIP_TRY(hipEventSynchronize(h->perm_ev));
     if (h->pf_thread.joinable()) h->pf_thread.join();
     const bool prefetched = !perm && h->pf_valid && h->pf_seed == seed && h->pf_M == M;
     h->pf_valid = false;
@@ -946,6 +949,8 @@ int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64
       }
     }
     HIP_TRY(hipMemcpyAsync(h->perm, h->perm_host.data(), M * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipEventRecord(h->perm_ev, h->stream));
+    h->perm_ev_used = true;
   }
   h->perm_cur = h->perm;
   return pass_begin_impl(h, batch_size);
