@@ -358,6 +358,28 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     return res, (T, N, D, K, gae_only)
 
 
+def copy_ceiling(dev, nbytes=1 << 30, reps=10):
+    """The box's stream-copy rate (reported for context, the fraction stays against 8 TB/s):
+    device-to-device copy of 1 GiB, read + write bytes counted, torch events on the current stream."""
+    import torch
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    src.zero_()
+    for _ in range(3):
+        dst.copy_(src)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    del src, dst
+    return {"value": 2 * nbytes / (ms * 1e-3) / 1e9, "unit": "GB/s",
+            "what": "Tensor.copy_ of 1 GiB on one device (the runtime's device-to-device copy), read + write bytes; a hand-written copy kernel reaches ~6.3 TB/s on this part (profiles/r1 membench)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -469,6 +491,11 @@ def main():
     if multi:
         dist.destroy_process_group()
     if rank == 0:
+        if world == 1:
+            try:
+                out["copy_ceiling"] = copy_ceiling(dev)
+            except Exception as e:          # context only: never costs the line
+                log(f"bench.py: copy ceiling not measured: {type(e).__name__}: {e}")
         if not args.no_cpu_baseline and world == 1 and not gae_only:
             out["cpu_baseline"] = cpu_baseline(T, N, D, K)
         sys.stdout.flush()
