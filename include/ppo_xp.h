@@ -317,7 +317,9 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams),
  * "gae_flat" 0/1 (1: the packing scan always stores the flat returns / advantages arrays too),
  * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),
- * "fused_block" 256/512 (its workgroup size).
+ * "fused_block" 256/512 (its workgroup size), "scalar_path" 0/1 (1: the partitioned scalar path of kernels_partition.h),
+ * "overlap" 0/1 (1: with the two-kernel path, the observation rows are gathered on a side stream of the handle while
+ * the scalar streams, statistics and standardisation run on its own; joined before the pass is handed out).
  * Unknown names or values => PPO_XP_EINVAL. */
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value);
 

@@ -142,6 +142,9 @@ struct ppo_xp {
   uint8_t *last_dones_pin = nullptr, *last_dones_pin_dev = nullptr;
   hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};
   hipEvent_t perm_ev = nullptr; bool perm_ev_used = false;       // marks the end of the last upload from perm_host
+  // split path with overlap: the observation rows are gathered on a side stream while the handle's stream runs the
+  // scalar streams, the statistics (and the exchange) and the standardisation; joined before the pass is handed out
+  hipStream_t side = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr; bool side_pending = false;
   unsigned pin_next = 0;
   const uint8_t *last_dones_cur = nullptr;   // device address of the slot of the current call
   float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
@@ -177,7 +180,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0;
 };
 
 namespace {
@@ -530,9 +533,36 @@ int normalize_range(ppo_xp *h, size_t Kn, const PassOut &o, bool fold = false, u
 }
 
 // ppo_xp_pass_finish and the tail of a sharded pass: the whole pass, statistics already in h->sums.
+// Observation rows on the side stream: ordered after everything the handle's stream holds now, joined by side_wait.
+int launch_obs_side(ppo_xp *h, size_t K, size_t B, size_t M, size_t k0, size_t Kn, float *obs_out) {
+  if (!h->side) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->side_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->side_join, hipEventDisableTiming));
+  }
+  HIP_TRY(hipEventRecord(h->side_fork, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->side, h->side_fork, 0));
+  hipStream_t mainstream = h->stream;
+  h->stream = h->side;
+  const int rc = launch_obs_gather(h, K, B, M, k0, Kn, obs_out);
+  h->stream = mainstream;
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(h->side_join, h->side));
+  h->side_pending = true;
+  return 0;
+}
+
+int side_wait(ppo_xp *h) {
+  if (!h->side_pending) return 0;
+  h->side_pending = false;
+  HIP_TRY(hipStreamWaitEvent(h->stream, h->side_join, 0));
+  return 0;
+}
+
 int pass_finish_impl(ppo_xp *h) {
   h->pass_pending_finish = false;
-  return normalize_range(h, h->pass_K, pass_out_at(h, 0, 0));
+  if (int rc = normalize_range(h, h->pass_K, pass_out_at(h, 0, 0))) return rc;
+  return side_wait(h);
 }
 
 // Gathers and standardises minibatches [k0, k0 + Kn) of the current pass into `o`.  Whole pass: k0 = 0, Kn = K;
@@ -601,6 +631,9 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
   g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
   const bool partitioned = whole && h->scalar_path == 1 && K * B == M && M >= kPartChunk &&
                            ((M + (size_t(1) << kSrcShift) - 1) >> kSrcShift) <= kMaxBins && ((M + (size_t(1) << kDstShift) - 1) >> kDstShift) <= kMaxBins;
+  const bool overlap = h->overlap != 0;
+  if (overlap)
+    if (int rc = launch_obs_side(h, K, B, M, k0, Kn, o.obs)) return rc;
   if (partitioned) {
     if (int rc = launch_partitioned_scalars(h, g, K, B, M)) return rc;
   } else {
@@ -620,11 +653,12 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
   if (h->xmode == 0) {
     // single GPU: standardise while the raw advantages are still in L2 / Infinity Cache, rows last
     if (int rc = normalize_range(h, Kn, o, fold)) return rc;
-    return launch_obs_gather(h, K, B, M, k0, Kn, o.obs);
+    return overlap ? side_wait(h) : launch_obs_gather(h, K, B, M, k0, Kn, o.obs);
   }
   // sharded: the observation rows do not depend on the statistics; enqueue them before the
   // exchange so that the all-reduce's host-side latency hides behind ~0.7 ms of GPU work
-  if (int rc = launch_obs_gather(h, K, B, M, k0, Kn, o.obs)) return rc;
+  if (!overlap)
+    if (int rc = launch_obs_gather(h, K, B, M, k0, Kn, o.obs)) return rc;
   if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
   int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
   if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
@@ -749,10 +783,14 @@ void ppo_xp_destroy(ppo_xp *h) {
   if (h->pf_thread.joinable()) h->pf_thread.join();
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->side) (void)hipStreamSynchronize(h->side);
   for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
   if (h->perm_ev) (void)hipEventDestroy(h->perm_ev);
+  if (h->side_fork) (void)hipEventDestroy(h->side_fork);
+  if (h->side_join) (void)hipEventDestroy(h->side_join);
+  if (h->side) (void)hipStreamDestroy(h->side);
   dev_free(h->obs); dev_free(h->rewards); dev_free(h->actions); dev_free(h->values); dev_free(h->dones);
   dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->done_bits); dev_free(h->perm);
   dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
@@ -1200,6 +1238,7 @@ int ppo_xp_set_stream(ppo_xp *h, void *stream) {
   if (!h) return fail(PPO_XP_EINVAL, "set_stream: handle is NULL");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->side_pending) HIP_TRY(hipStreamSynchronize(h->side));   // its join event stays valid for the new stream
   if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
   h->stream = (hipStream_t)stream;
   return 0;
@@ -1244,6 +1283,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "gae_waves" && (value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) h->gae_waves = value;
   else if (n == "summary_nt" && (value == 0 || value == 1)) h->summary_nt = value;
   else if (n == "gae_nt" && (value == 0 || value == 1)) h->gae_nt = value;
+  else if (n == "overlap" && (value == 0 || value == 1)) h->overlap = value;
   else if (n == "gae_flat" && (value == 0 || value == 1)) h->gae_flat = value;
   else if (n == "fused" && value >= -1 && value <= 1) h->fused = value;
   else if (n == "fused_block" && (value == 256 || value == 512)) h->fused_block = value;

@@ -45,6 +45,7 @@ def test_random_configurations(xp, oracle, chunk):
         buf.set_tunable("fused", int(g.choice([-1, 0, 1])))
         buf.set_tunable("fused_block", int(g.choice([256, 512])))
         buf.set_tunable("scalar_path", int(g.choice([0, 1])))
+        buf.set_tunable("overlap", int(g.choice([0, 1])))
         M = len(orc) * N
         perm = None
         seed = int(g.integers(1 << 62))
