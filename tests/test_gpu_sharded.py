@@ -28,9 +28,10 @@ def _fill(buf, r, sl=slice(None)):
                  c(r["dones"][:, sl]), c(r["neglogps"][:, sl]))
 
 
-@pytest.mark.parametrize("T,N,D,B", [(24, 96, 8, 500),        # scalar_gather_kernel + obs_gather_kernel
-                                     (16, 128, 64, 512)])     # fused_gather_kernel (32 rows per workgroup)
-def test_exchange_modes_agree_on_one_rank(T, N, D, B):
+@pytest.mark.parametrize("T,N,D,B,overlap", [(24, 96, 8, 500, 0),     # scalar_gather_kernel + obs_gather_kernel
+                                             (24, 96, 8, 500, 1),     # the same with the rows on the side stream
+                                             (16, 128, 64, 512, 0)])  # fused_gather_kernel (32 rows per workgroup)
+def test_exchange_modes_agree_on_one_rank(T, N, D, B, overlap):
     import torch
     import ppo_amd
     from ppo_amd import _lib, synth
@@ -39,6 +40,8 @@ def test_exchange_modes_agree_on_one_rank(T, N, D, B):
     L = _lib.load()
     for mode in (0, 2, 1):
         buf = ppo_amd.ExperienceBuffer(N, D, T)
+        if mode:
+            buf.set_tunable("overlap", overlap)
         _fill(buf, r)
         buf.returns(r["last_dones"])
         comm = C.c_void_p()
