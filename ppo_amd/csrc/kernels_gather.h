@@ -35,6 +35,51 @@ template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = f32x2; };
 template <> struct VecT<4> { using type = f32x4; };
 
+// ---- device-resident insert (buffer.rs:84-121 for rows that are already on the GPU) ----------------------
+// ONE launch per inserted row instead of six copies and two pack kernels: the first obs_blocks workgroups copy
+// the observation row, the rest copy the five scalar rows and keep the records' static halves and the done
+// bits in step (what pack_static_kernel / pack_done_bits_kernel do for the host-side insert).
+struct InsertArgs {
+  const float *obs, *rewards, *values, *dones, *neglogps;   // source rows: [N, D], [N] x 4
+  const int64_t *actions;                                    // [N]
+  float *obs_dst, *rew_dst, *val_dst, *done_dst, *nlp_dst;  // row `idx` of the buffer's streams
+  int64_t *act_dst;
+  Rec *rec;                                                  // whole record array
+  uint32_t *bits_row;                                        // done bits of row idx: [W]
+  size_t i0;                                                 // flat index of the row's first transition (idx * N)
+  size_t obs_elems;                                          // elements (of V floats) in the observation row
+  unsigned N, W, obs_blocks;
+};
+
+template <int V>
+__global__ __launch_bounds__(256) void insert_row_kernel(const InsertArgs a) {
+  using T = typename VecT<V>::type;
+  if (blockIdx.x < a.obs_blocks) {
+    const size_t j = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (j < a.obs_elems)
+      __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const T *>(a.obs) + j), reinterpret_cast<T *>(a.obs_dst) + j);
+    return;
+  }
+  const unsigned e = (blockIdx.x - a.obs_blocks) * 256u + threadIdx.x, e0 = e & ~63u;
+  bool d = false;
+  if (e < a.N) {
+    const float df = a.dones[e], nlp = a.neglogps[e];
+    const int64_t act = a.actions[e];
+    d = df != 0.0f;
+    a.rew_dst[e] = a.rewards[e];
+    a.val_dst[e] = a.values[e];
+    a.done_dst[e] = df;
+    a.nlp_dst[e] = nlp;
+    a.act_dst[e] = act;
+    store_rec_static(a.rec, a.i0 + e, nlp, act);
+  }
+  const unsigned long long m = __ballot(d);
+  if ((threadIdx.x & 63u) == 0 && e0 < a.N) {
+    a.bits_row[e0 >> 5] = (uint32_t)m;
+    if ((e0 >> 5) + 1 < a.W) a.bits_row[(e0 >> 5) + 1] = (uint32_t)(m >> 32);
+  }
+}
+
 struct ObsGatherArgs {
   const float *obs;        // [M, D]
   const uint32_t *perm;    // [M]

@@ -874,13 +874,26 @@ int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const i
   if (!obs || !rewards || !actions || !vals || !dones_f32 || !neglogps) return fail(PPO_XP_EINVAL, "add_device: NULL input");
   HIP_TRY(hipSetDevice(h->device));
   const size_t N = h->N, D = h->D, idx = h->counter % h->capacity;
-  HIP_TRY(hipMemcpyAsync(h->obs + idx * N * D, obs, N * D * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->rewards + idx * N, rewards, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->actions + idx * N, actions, N * sizeof(int64_t), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->values + idx * N, vals, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->dones + idx * N, dones_f32, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->neglogps + idx * N, neglogps, N * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
-  if (int rc = pack_static_rows(h, idx, 1)) return rc;
+  if (N > 0xffffff00ull) return fail(PPO_XP_EINVAL, "add_device: %zu envs do not fit one launch", N);
+  InsertArgs a{};
+  a.obs = obs; a.rewards = rewards; a.values = vals; a.dones = dones_f32; a.neglogps = neglogps; a.actions = actions;
+  a.obs_dst = h->obs + idx * N * D; a.rew_dst = h->rewards + idx * N; a.val_dst = h->values + idx * N;
+  a.done_dst = h->dones + idx * N; a.nlp_dst = h->neglogps + idx * N; a.act_dst = h->actions + idx * N;
+  a.rec = h->rec; a.W = (unsigned)((N + 31) / 32); a.bits_row = h->done_bits + idx * a.W;
+  a.i0 = idx * N; a.N = (unsigned)N;
+  // 16-byte elements when the row and both of its ends allow it (hipMalloc'ed bases are 256-byte aligned; the
+  // buffer's row starts at idx * N * D floats, the caller's pointer is whatever it is)
+  const size_t row = N * D;
+  const bool v4 = row % 4 == 0 && ((uintptr_t)obs % 16) == 0 && ((uintptr_t)a.obs_dst % 16) == 0;
+  a.obs_elems = v4 ? row / 4 : row;
+  const size_t ob = (a.obs_elems + 255) / 256, sb = (N + 255) / 256;
+  if (ob + sb > 0x7fffffffull) return fail(PPO_XP_EINVAL, "add_device: row too large for one launch (%zu workgroups)", ob + sb);
+  a.obs_blocks = (unsigned)ob;
+  if (ob + sb) {
+    if (v4) hipLaunchKernelGGL((insert_row_kernel<4>), dim3((unsigned)(ob + sb)), dim3(256), 0, h->stream, a);
+    else hipLaunchKernelGGL((insert_row_kernel<1>), dim3((unsigned)(ob + sb)), dim3(256), 0, h->stream, a);
+    if (int rc = launch_check("insert_row_kernel")) return rc;
+  }
   advance_counter(h, idx);
   return 0;
 }

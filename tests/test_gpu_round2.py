@@ -316,3 +316,33 @@ def test_streaming_mode_matches_the_whole_pass(xp, oracle, T, N, D, B, fused):
     with pytest.raises(xp.PpoXpError):
         g.set_streaming(True)
     g.close()
+
+
+@pytest.mark.parametrize("N,D,cap,steps,offset", [(37, 3, 5, 12, 0),      # ragged: scalar elements, ring wraps twice
+                                                  (100, 6, 7, 7, 0),      # row = 600 floats: 16-byte elements
+                                                  (64, 8, 4, 9, 1),       # source rows start 4 bytes off a 16-byte boundary
+                                                  (300, 64, 6, 6, 0)])    # several scalar workgroups, fused-gather shape
+def test_device_insert_single_launch(xp, oracle, N, D, cap, steps, offset):
+    """ppo_xp_add_device is ONE kernel per row (rows, scalar streams, the records' static halves and the done bits):
+    ragged shapes, unaligned sources, 64-bit actions and ring wrap against the oracle's add_experience
+    (buffer.rs:84-121), then a whole pass so that the records and the done bits are read back."""
+    import torch
+    from ppo_amd import synth
+    from test_gpu_parity import check_pass
+    r = synth.rollout(steps, N, D, 1234 + N, 0.2)
+    r["actions"][:, ::5] = (1 << 40) + 3                      # does not fit the record's 32 bits: escape path
+    g, o = xp.ExperienceBuffer(N, D, cap), oracle.OracleBuffer(N, D, cap)
+    for t in range(steps):
+        def dev(a, dt):
+            flat = torch.empty(a.size + offset, dtype=dt, device="cuda")
+            v = flat[offset:].view(a.shape)
+            v.copy_(torch.from_numpy(np.ascontiguousarray(a).astype({torch.float32: np.float32, torch.int64: np.int64}[dt])))
+            return v
+        g.add_experience_device(dev(r["obs"][t], torch.float32), dev(r["rewards"][t], torch.float32),
+                                dev(r["actions"][t], torch.int64), dev(r["values"][t], torch.float32),
+                                dev(r["dones"][t], torch.float32), dev(r["neglogps"][t], torch.float32))
+        o.add_experience(r["obs"][t], r["rewards"][t], r["actions"][t], r["values"][t], r["dones"][t], r["neglogps"][t])
+    assert len(g) == len(o)
+    M = len(o) * N
+    check_pass(xp, oracle, g, o, r["last_dones"], max(1, M // 3), seed=5)
+    g.close()
