@@ -116,7 +116,10 @@ void ppo_xp_destroy(ppo_xp *h);
 
 /* ExperienceBuffer::add_experience (buffer.rs:84-121).  Host pointers; obs is [n, obs_size],
  * the rest [n]; dones are Rust bools (1 byte, 0/1).  n != num_envs => PPO_XP_EINVAL (the
- * reference panics, buffer.rs:97-112). */
+ * reference panics, buffer.rs:97-112).  The host arrays are the caller's again when the call returns.
+ * Rows of up to 256 KiB (all six arrays) are copied into a page-locked slot of the handle and inserted by one
+ * kernel that reads the slot over the bus: the call does not wait for the GPU (later calls on the handle are
+ * ordered after it); larger rows take one copy command per array and the call waits for them. */
 int ppo_xp_add(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions,
                const float *vals, const uint8_t *dones, const float *neglogps, size_t n);
 /* `steps` consecutive add_experience calls from [steps, n, ...] host arrays (same ring
@@ -126,7 +129,7 @@ int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const siz
                     size_t steps);
 /* add_experience with DEVICE source rows (device-resident simulators / policies);
  * dones_f32 exactly 0.0 or 1.0 as the reference stores them (buffer.rs:95; the scans read the flags as
- * bits, any non-zero value counts as done).  The six copies are ENQUEUED on the handle's stream and the call
+ * bits, any non-zero value counts as done).  The insert (one kernel per row) is ENQUEUED on the handle's stream and the call
  * returns without waiting: the source arrays must stay valid and unchanged until that stream has
  * passed them (ppo_xp_sync(), or an event recorded on ppo_xp_stream() after the call), and whatever
  * produced them must be ordered before the call (same stream, or synchronised).  The Python mirror

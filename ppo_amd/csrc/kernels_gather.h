@@ -41,6 +41,8 @@ template <> struct VecT<4> { using type = f32x4; };
 // bits in step (what pack_static_kernel / pack_done_bits_kernel do for the host-side insert).
 struct InsertArgs {
   const float *obs, *rewards, *values, *dones, *neglogps;   // source rows: [N, D], [N] x 4
+  const uint8_t *dones_u8;                                   // when set: the done flags as Rust bools instead of `dones`
+                                                             // (`dones[i] as u8 as f32`, buffer.rs:95)
   const int64_t *actions;                                    // [N]
   float *obs_dst, *rew_dst, *val_dst, *done_dst, *nlp_dst;  // row `idx` of the buffer's streams
   int64_t *act_dst;
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void insert_row_kernel(const InsertArgs a) {
   const unsigned e = (blockIdx.x - a.obs_blocks) * 256u + threadIdx.x, e0 = e & ~63u;
   bool d = false;
   if (e < a.N) {
-    const float df = a.dones[e], nlp = a.neglogps[e];
+    const float df = a.dones_u8 ? (a.dones_u8[e] != 0 ? 1.0f : 0.0f) : a.dones[e], nlp = a.neglogps[e];
     const int64_t act = a.actions[e];
     d = df != 0.0f;
     a.rew_dst[e] = a.rewards[e];

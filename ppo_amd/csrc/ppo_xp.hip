@@ -121,6 +121,8 @@ int scratch_for_device(int device, float **out) {
 // ---------------------------------------------------------------------------------------
 // handle
 // ---------------------------------------------------------------------------------------
+constexpr size_t kStageSlots = 8, kStageSlotBytes = size_t(256) << 10;   // staging of small host rows (ppo_xp_add)
+
 struct ProfRec { int kid; hipEvent_t a, b; };
 
 struct ppo_xp {
@@ -141,6 +143,10 @@ struct ppo_xp {
   // is reused 8 calls later; one event per 4 calls (two alternate) tells when those scans have run.
   uint8_t *last_dones_pin = nullptr, *last_dones_pin_dev = nullptr;
   hipEvent_t pin_ev[2] = {nullptr, nullptr}; bool pin_used[2] = {false, false};
+  // small host rows (ppo_xp_add) are staged in page-locked, device-visible slots and inserted by ONE kernel that reads
+  // them over the bus: no copy commands, no synchronisation.  Slots of block b (4 slots) are reused after its event.
+  uint8_t *stage_pin = nullptr, *stage_pin_dev = nullptr; unsigned stage_next = 0;
+  hipEvent_t stage_ev[2] = {nullptr, nullptr}; bool stage_used[2] = {false, false};
   hipEvent_t perm_ev = nullptr; bool perm_ev_used = false;       // marks the end of the last upload from perm_host
   // split path with overlap: the observation rows are gathered on a side stream while the handle's stream runs the
   // scalar streams, the statistics (and the exchange) and the standardisation; joined before the pass is handed out
@@ -764,11 +770,17 @@ int ppo_xp_create(ppo_xp **out, int device, size_t capacity, size_t num_envs, si
     rc = fail(PPO_XP_ENOMEM, "create: hipHostMalloc failed");
   if (!rc && hipHostGetDevicePointer((void **)&h->last_dones_pin_dev, h->last_dones_pin, 0) != hipSuccess)
     rc = fail(PPO_XP_EIO, "create: hipHostGetDevicePointer failed");
+  if (!rc && hipHostMalloc((void **)&h->stage_pin, kStageSlots * kStageSlotBytes, hipHostMallocMapped) != hipSuccess)
+    rc = fail(PPO_XP_ENOMEM, "create: hipHostMalloc failed");
+  if (!rc && hipHostGetDevicePointer((void **)&h->stage_pin_dev, h->stage_pin, 0) != hipSuccess)
+    rc = fail(PPO_XP_EIO, "create: hipHostGetDevicePointer failed");
   if (!rc && hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
     rc = fail(PPO_XP_EIO, "create: hipStreamCreate failed");
   if (!rc) h->own_stream = true;
   for (int i = 0; i < 2 && !rc; ++i)
     if (hipEventCreateWithFlags(&h->pin_ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
+  for (int i = 0; i < 2 && !rc; ++i)
+    if (hipEventCreateWithFlags(&h->stage_ev[i], hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
   if (!rc && hipEventCreateWithFlags(&h->perm_ev, hipEventDisableTiming) != hipSuccess) rc = fail(PPO_XP_EIO, "create: hipEventCreate failed");
   if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail(PPO_XP_EIO, "create: device sync failed");
   // set-up of the allocation-free entry point: this device's address of the static scratch
@@ -787,6 +799,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
+  for (auto e : h->stage_ev) if (e) (void)hipEventDestroy(e);
   if (h->perm_ev) (void)hipEventDestroy(h->perm_ev);
   if (h->side_fork) (void)hipEventDestroy(h->side_fork);
   if (h->side_join) (void)hipEventDestroy(h->side_join);
@@ -800,6 +813,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   if (h->shuffle_ws) { (void)hipFree(h->shuffle_ws); h->shuffle_ws = nullptr; }
   if (h->part_ws) { (void)hipFree(h->part_ws); h->part_ws = nullptr; }
   if (h->last_dones_pin) (void)hipHostFree(h->last_dones_pin);
+  if (h->stage_pin) (void)hipHostFree(h->stage_pin);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -862,21 +876,13 @@ int ppo_xp_add_many(ppo_xp *h, const float *obs, const float *rewards, const siz
   return 0;
 }
 
-int ppo_xp_add(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions, const float *vals,
-               const uint8_t *dones, const float *neglogps, size_t n) {
-  return ppo_xp_add_many(h, obs, rewards, actions, vals, dones, neglogps, n, 1);
-}
-
-int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions, const float *vals,
-                      const float *dones_f32, const float *neglogps, size_t n) {
-  if (!h) return fail(PPO_XP_EINVAL, "add_device: handle is NULL");
-  if (n != h->N) return fail(PPO_XP_EINVAL, "add_experience: %zu envs given, buffer has %zu", n, h->N);
-  if (!obs || !rewards || !actions || !vals || !dones_f32 || !neglogps) return fail(PPO_XP_EINVAL, "add_device: NULL input");
-  HIP_TRY(hipSetDevice(h->device));
+// One inserted row by one kernel: sources are device-visible pointers (device memory or staged host slots).
+static int launch_insert_row(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions, const float *vals,
+                             const float *dones_f32, const uint8_t *dones_u8, const float *neglogps) {
   const size_t N = h->N, D = h->D, idx = h->counter % h->capacity;
-  if (N > 0xffffff00ull) return fail(PPO_XP_EINVAL, "add_device: %zu envs do not fit one launch", N);
+  if (N > 0xffffff00ull) return fail(PPO_XP_EINVAL, "add: %zu envs do not fit one launch", N);
   InsertArgs a{};
-  a.obs = obs; a.rewards = rewards; a.values = vals; a.dones = dones_f32; a.neglogps = neglogps; a.actions = actions;
+  a.obs = obs; a.rewards = rewards; a.values = vals; a.dones = dones_f32; a.dones_u8 = dones_u8; a.neglogps = neglogps; a.actions = actions;
   a.obs_dst = h->obs + idx * N * D; a.rew_dst = h->rewards + idx * N; a.val_dst = h->values + idx * N;
   a.done_dst = h->dones + idx * N; a.nlp_dst = h->neglogps + idx * N; a.act_dst = h->actions + idx * N;
   a.rec = h->rec; a.W = (unsigned)((N + 31) / 32); a.bits_row = h->done_bits + idx * a.W;
@@ -887,7 +893,7 @@ int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const i
   const bool v4 = row % 4 == 0 && ((uintptr_t)obs % 16) == 0 && ((uintptr_t)a.obs_dst % 16) == 0;
   a.obs_elems = v4 ? row / 4 : row;
   const size_t ob = (a.obs_elems + 255) / 256, sb = (N + 255) / 256;
-  if (ob + sb > 0x7fffffffull) return fail(PPO_XP_EINVAL, "add_device: row too large for one launch (%zu workgroups)", ob + sb);
+  if (ob + sb > 0x7fffffffull) return fail(PPO_XP_EINVAL, "add: row too large for one launch (%zu workgroups)", ob + sb);
   a.obs_blocks = (unsigned)ob;
   if (ob + sb) {
     if (v4) hipLaunchKernelGGL((insert_row_kernel<4>), dim3((unsigned)(ob + sb)), dim3(256), 0, h->stream, a);
@@ -896,6 +902,47 @@ int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const i
   }
   advance_counter(h, idx);
   return 0;
+}
+
+static size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+int ppo_xp_add(ppo_xp *h, const float *obs, const float *rewards, const size_t *actions, const float *vals,
+               const uint8_t *dones, const float *neglogps, size_t n) {
+  if (!h) return fail(PPO_XP_EINVAL, "add: handle is NULL");
+  const size_t N = h->N, D = h->D;
+  // layout of one staged row: obs | rewards | values | neglogps | actions | dones, every part 16-byte aligned
+  const size_t o_rew = align16(N * D * 4), o_val = o_rew + align16(N * 4), o_nlp = o_val + align16(N * 4),
+               o_act = o_nlp + align16(N * 4), o_don = o_act + align16(N * 8), total = o_don + align16(N);
+  if (n != N || total > kStageSlotBytes || !obs || !rewards || !actions || !vals || !dones || !neglogps)
+    return ppo_xp_add_many(h, obs, rewards, actions, vals, dones, neglogps, n, 1);   // large rows (copy commands) and every error message
+  HIP_TRY(hipSetDevice(h->device));
+  const unsigned call = h->stage_next++;
+  const unsigned slot = call % kStageSlots, blk = (call >> 2) & 1u;
+  if ((call & 3u) == 0 && h->stage_used[blk]) HIP_TRY(hipEventSynchronize(h->stage_ev[blk]));
+  uint8_t *s = h->stage_pin + slot * kStageSlotBytes;
+  const uint8_t *d = h->stage_pin_dev + slot * kStageSlotBytes;
+  std::memcpy(s, obs, N * D * 4);
+  std::memcpy(s + o_rew, rewards, N * 4);
+  std::memcpy(s + o_val, vals, N * 4);
+  std::memcpy(s + o_nlp, neglogps, N * 4);
+  std::memcpy(s + o_act, actions, N * 8);
+  std::memcpy(s + o_don, dones, N);
+  const int rc = launch_insert_row(h, (const float *)d, (const float *)(d + o_rew), (const int64_t *)(d + o_act), (const float *)(d + o_val),
+                                   nullptr, d + o_don, (const float *)(d + o_nlp));
+  if ((call & 3u) == 3u) {          // also after a failed launch: the slots of this block may still be read
+    HIP_TRY(hipEventRecord(h->stage_ev[blk], h->stream));
+    h->stage_used[blk] = true;
+  }
+  return rc;
+}
+
+int ppo_xp_add_device(ppo_xp *h, const float *obs, const float *rewards, const int64_t *actions, const float *vals,
+                      const float *dones_f32, const float *neglogps, size_t n) {
+  if (!h) return fail(PPO_XP_EINVAL, "add_device: handle is NULL");
+  if (n != h->N) return fail(PPO_XP_EINVAL, "add_experience: %zu envs given, buffer has %zu", n, h->N);
+  if (!obs || !rewards || !actions || !vals || !dones_f32 || !neglogps) return fail(PPO_XP_EINVAL, "add_device: NULL input");
+  HIP_TRY(hipSetDevice(h->device));
+  return launch_insert_row(h, obs, rewards, actions, vals, dones_f32, nullptr, neglogps);
 }
 
 void *ppo_xp_host_alloc(size_t bytes) {
