@@ -186,7 +186,8 @@ int ppo_xp_explained_variance_from_sums(const double *sums5, float *out);
 /* ExperienceBuffer::training_views (buffer.rs:142-175) + the batcher's master set.  A pass reads the
  * GAE results from packed records, so ppo_xp_returns(host_out = NULL) does not store the flat returns /
  * advantages arrays; the first call here after such a ppo_xp_returns enqueues the small kernel that
- * unpacks them on the handle's stream (same bits: ret as stored, adv' = fl(ret - v), data.rs:62). */
+ * unpacks them on the handle's stream (same bits: ret as stored, adv' = fl(ret - v), data.rs:62).
+ * Inserts and scans are only enqueued on that stream: read the views on it (ppo_xp_stream) or after ppo_xp_sync(). */
 int ppo_xp_views(const ppo_xp *h, ppo_xp_views_t *out);
 
 /* ---- one shuffled pass over the buffer (IntoIterator + Iterator, data.rs:85-193) ------- */
