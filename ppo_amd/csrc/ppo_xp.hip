@@ -676,6 +676,7 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   const size_t len = buf_len(h), M = len * h->N;
   if (!h->have_returns || h->ret_len != len)
     return fail(PPO_XP_ESTATE, "pass_begin: call ppo_xp_returns() first (ExperienceBatcher::new takes the returns, data.rs:27)");
+  if (int rc = side_wait(h)) return rc;                      // rows of an abandoned pass (begun, never finished) on the side stream
   h->pass_B = B; h->pass_M = M; h->pass_iter = 0; h->pass_active = true; h->pass_pending_finish = false;
   h->pass_K = (B > M) ? 0 : (M + B - 1) / B;                 // data.rs:117-126
   h->pass_streamed = h->streaming;
