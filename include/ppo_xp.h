@@ -212,6 +212,15 @@ int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_
  * argsort of key_i = SplitMix64(seed, i).  A uniform permutation like the reference's, but NOT the
  * sequence rand's shuffle would give for this seed; reproducible, with a CPU twin in the oracle. */
 int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed);
+/* Same, with the permutation given by a KEYED BIJECTION of (seed, M) that the gather kernels evaluate in registers
+ * (ppo_amd/csrc/bijection.h: six alternating Feistel steps on max(8, ceil(log2 M)) bits, cycle-walked into [0, M)):
+ * into_iter() (data.rs:91-102) without an index array - nothing is drawn, sorted, uploaded or read, so permutation
+ * generation is part of the pass itself.  When the fused gather runs (rows and scalar streams in one kernel) perm(j) is
+ * computed once per output row; the kernels that read an index array (wide rows, records beyond the Infinity Cache)
+ * get it written out first by one small launch.  ppo_xp_pass_perm_device / _host write it out on demand.  A keyed
+ * pseudo-random permutation like the reference's shuffle (uniformity checked in tests/), not rand's sequence;
+ * reproducible, with CPU twins in the oracle (C and numpy), indices bit-equal. */
+int ppo_xp_pass_begin_bijection(ppo_xp *h, size_t batch_size, uint64_t seed);
 /* Iterator::next (data.rs:115-192): 0 = *out filled, 1 = exhausted (`None`), < 0 error.
  * The windows follow data.rs:121-126 exactly, including the overlapping tail batch.
  * Whole-pass mode (default): ppo_xp_pass_begin* gathered every minibatch, this only hands out slices of the slabs.
@@ -321,7 +330,9 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams),
  * "gae_flat" 0/1 (1: the packing scan always stores the flat returns / advantages arrays too),
  * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),
- * "fused_block" 256/512 (its workgroup size), "scalar_path" 0/1 (1: the partitioned scalar path of kernels_partition.h),
+ * "fused_block" 256/512 (its workgroup size), "bij_mode" 0/1/2 (keyed-bijection passes: 0 = always write the index
+ * array out first, 1 = one evaluation per output row handed to the row's threads through LDS, 2 = every thread evaluates
+ * its own), "scalar_path" 0/1 (1: the partitioned scalar path of kernels_partition.h),
  * "overlap" 0/1 (1: with the two-kernel path, the observation rows are gathered on a side stream of the handle while
  * the scalar streams, statistics and standardisation run on its own; joined before the pass is handed out).
  * Unknown names or values => PPO_XP_EINVAL. */

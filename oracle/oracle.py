@@ -73,6 +73,10 @@ def lib() -> C.CDLL:
         L.orc_run_path.argtypes = [vp] * 6 + [sz, sz, sz, sz, vp, f32, f32, vp, sz] + [vp] * 8 + [i32]
         L.orc_keyed_shuffle.restype = i32
         L.orc_keyed_shuffle.argtypes = [u64, sz, vp]
+        L.orc_bijection_perm.restype = i32
+        L.orc_bijection_perm.argtypes = [u64, sz, vp]
+        L.orc_bijection_range.restype = i32
+        L.orc_bijection_range.argtypes = [u64, sz, sz, sz, i32, vp]
         L.orc_var_welford_f32.restype = f32
         L.orc_var_welford_f32.argtypes = [vp, sz, f32]
         L.orc_explained_variance.restype = f32
@@ -296,6 +300,59 @@ def np_keyed_shuffle(seed, M):
         z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
         z = z ^ (z >> np.uint64(31))
     return np.argsort(z, kind="stable").astype(np.uint32)
+
+
+def bijection_perm(seed, M, inverse=False):
+    """CPU twin of ppo_xp_pass_begin_bijection: perm(j) (or perm^-1) for every j < M — a keyed Feistel network on
+    max(8, ceil(log2 M)) bits, cycle-walked into [0, M) (not in the reference: data.rs:91-96 is the host shuffle)."""
+    out = np.empty(M, np.uint32)
+    if M:
+        assert lib().orc_bijection_range(seed, M, 0, M, int(bool(inverse)), _p(out)) == 0
+    return out
+
+
+def bijection_range(seed, M, first, count, inverse=False):
+    out = np.empty(count, np.uint32)
+    assert lib().orc_bijection_range(seed, M, first, count, int(bool(inverse)), _p(out)) == 0
+    return out
+
+
+def np_bijection_perm(seed, M, inverse=False):
+    """Independent numpy restatement of bijection_perm (vectorised; the walk repeats on the entries still >= M)."""
+    u = np.uint64
+    with np.errstate(over="ignore"):
+        z = u(seed) + (np.arange(6, dtype=u) + u(1)) * u(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> u(30))) * u(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> u(27))) * u(0x94D049BB133111EB)
+        keys = (z ^ (z >> u(31))) >> u(32)
+    n = max(8, int(M - 1).bit_length()) if M else 8
+    lo_bits = n // 2
+    hi_mask, lo_mask = u((1 << (n - lo_bits)) - 1), u((1 << lo_bits) - 1)
+    m24, m32 = u(0xFFFFFF), u(0xFFFFFFFF)
+
+    def fn(v, k):
+        t = v ^ (k & u(0xFFFF))
+        t = ((t & m24) * u(0xE995)) & m32
+        t = t ^ (t >> u(15))
+        t = ((t & m24) * u(0x2C1B3)) & m32
+        t = t ^ (t >> u(13))
+        return (t + (k >> u(16))) & m32
+
+    def network(x):
+        hi, lo = x >> u(lo_bits), x & lo_mask
+        for r in (range(5, -1, -1) if inverse else range(6)):
+            if r % 2 == 0:
+                hi = hi ^ (fn(lo, keys[r]) & hi_mask)
+            else:
+                lo = lo ^ (fn(hi, keys[r]) & lo_mask)
+        return (hi << u(lo_bits)) | lo
+
+    x = network(np.arange(M, dtype=u))
+    todo = np.nonzero(x >= u(M))[0]
+    while todo.size:
+        x[todo] = network(x[todo])
+        todo = todo[x[todo] >= u(M)]
+    return x.astype(np.uint32)
 
 
 def explained_variance(values, returns):

@@ -453,6 +453,66 @@ int orc_keyed_shuffle(uint64_t seed, size_t M, uint32_t *indices) {
   return 0;
 }
 
+/* CPU twin of the KEYED BIJECTION pass (ppo_xp_pass_begin_bijection; not in the reference, whose
+ * shuffle is the host Fisher-Yates above, data.rs:91-96).  perm(j) is evaluated from (seed, M) alone:
+ * six alternating Feistel steps on n = max(8, ceil(log2 M)) bits, x = (a << l) | b with l = n / 2,
+ *   step r even: a ^= f(b, key_r) & hmask      step r odd: b ^= f(a, key_r) & lmask
+ *   f(v, k) = mix of two 24-bit multiplies (below),  key_r = high half of the r-th SplitMix64 output,
+ * cycle-walked into [0, M).  Each step is its own inverse, so perm^-1 runs them backwards.
+ * Written from that specification, independently of the device header. */
+#define ORC_BIJ_ROUNDS 6
+typedef struct { uint32_t M, l, hmask, lmask, key[ORC_BIJ_ROUNDS]; } orc_bij;
+
+static uint32_t orc_mul24(uint32_t a, uint32_t b) {
+  return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull);
+}
+
+static uint32_t orc_bij_round_fn(uint32_t v, uint32_t key) {
+  uint32_t t = v ^ (key & 0xFFFFu);
+  t = orc_mul24(t, 0xE995u);
+  t = t ^ (t >> 15);
+  t = orc_mul24(t, 0x2C1B3u);
+  t = t ^ (t >> 13);
+  return t + (key >> 16);
+}
+
+static void orc_bij_init(orc_bij *b, uint64_t seed, size_t M) {
+  unsigned n = 8;
+  while (n < 32 && ((uint64_t)1 << n) < (uint64_t)M) n++;
+  const unsigned l = n / 2, h = n - l;
+  b->M = (uint32_t)M; b->l = l;
+  b->hmask = (uint32_t)(((uint64_t)1 << h) - 1);
+  b->lmask = (uint32_t)(((uint64_t)1 << l) - 1);
+  for (unsigned r = 0; r < ORC_BIJ_ROUNDS; ++r) b->key[r] = (uint32_t)(orc_splitmix64_at(seed, r) >> 32);
+}
+
+static uint32_t orc_bij_network(const orc_bij *b, uint32_t x, int backwards) {
+  uint32_t hi = x >> b->l, lo = x & b->lmask;
+  for (int s = 0; s < ORC_BIJ_ROUNDS; ++s) {
+    const int r = backwards ? ORC_BIJ_ROUNDS - 1 - s : s;
+    if (r % 2 == 0) hi ^= orc_bij_round_fn(lo, b->key[r]) & b->hmask;
+    else lo ^= orc_bij_round_fn(hi, b->key[r]) & b->lmask;
+  }
+  return (hi << b->l) | lo;
+}
+
+/* out[j] = perm(j) (inverse = 0) or perm^-1(j) (inverse = 1) for j in [first, first + count). */
+int orc_bijection_range(uint64_t seed, size_t M, size_t first, size_t count, int inverse, uint32_t *out) {
+  if (M == 0 || M > 0xFFFFFFFFull || first + count > M) return -1;
+  orc_bij b; orc_bij_init(&b, seed, M);
+  for (size_t j = 0; j < count; ++j) {
+    uint32_t x = (uint32_t)(first + j);
+    do x = orc_bij_network(&b, x, inverse); while (x >= b.M);
+    out[j] = x;
+  }
+  return 0;
+}
+
+int orc_bijection_perm(uint64_t seed, size_t M, uint32_t *indices) {
+  if (M == 0) return 0;
+  return orc_bijection_range(seed, M, 0, M, 0, indices);
+}
+
 /* ndarray 0.15.6 `var_axis(Axis(0), ddof)` on a 1-D f32 array (used by explained_variance,
  * ppo/src/training.rs:91,96): sequential Welford with a fused multiply-add,
  *   delta = x - mean; mean += delta / count; sum_sq = (x - mean).mul_add(delta, sum_sq); -> sum_sq / (n - ddof).

@@ -73,6 +73,7 @@ SYMBOLS = {
     "ppo_xp_pass_begin": (_i, [_vp, _sz, _vp, _u64]),
     "ppo_xp_pass_begin_device": (_i, [_vp, _sz, _vp]),
     "ppo_xp_pass_begin_device_shuffle": (_i, [_vp, _sz, _u64]),
+    "ppo_xp_pass_begin_bijection": (_i, [_vp, _sz, _u64]),
     "ppo_xp_explained_variance": (_i, [_vp, C.POINTER(C.c_float)]),
     "ppo_xp_explained_variance_sums": (_i, [_vp, C.POINTER(C.c_double)]),
     "ppo_xp_explained_variance_from_sums": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_float)]),

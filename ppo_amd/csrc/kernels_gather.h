@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "bijection.h"
 #include "kernels_gae.h"
 
 namespace ppoxp {
@@ -231,24 +232,46 @@ struct FusedGatherArgs {
   ObsGatherArgs o;
   ScalarGatherArgs s;
   unsigned rpw;            // rows per workgroup = BS / Q  (<= 64) = rows per statistics tile
+  Bijection bij;           // BIJ != 0: perm(j) is evaluated from this, o.perm / s.perm are not read
 };
 
-template <int BS, bool NT, bool TAIL>
+// BIJ = 0: the permutation is an array (o.perm).  BIJ = 1: keyed bijection (bijection.h), evaluated ONCE per output row
+// by the first rpw lanes of wave 0 (the lanes that also gather the row's scalar streams), handed to the row's threads
+// through LDS: no index array is written, uploaded or read, and no thread waits for an index load before it can issue
+// its row load.  BIJ = 2: every thread evaluates its own row's index (no LDS, no barrier; 8x the integer work).
+template <int BS, bool NT, bool TAIL, int BIJ = 0>
 __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
+  __shared__ uint32_t src_row[64];
   const unsigned Q = g.o.Q, rpw = g.rpw;
   const size_t row0 = (size_t)blockIdx.x * rpw;
   const size_t KB = g.o.total >> g.o.qshift;                  // K*B output rows
+  uint32_t p_lane = 0;                                        // BIJ = 1: source row of output row row0 + lane (wave 0)
+  if (BIJ == 1) {
+    if (threadIdx.x < rpw && row0 + threadIdx.x < KB) {
+      size_t pos = g.o.row_base + row0 + threadIdx.x;
+      if (TAIL) {
+        const size_t k = pos / g.o.B, start = k * g.o.B;
+        if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
+      }
+      p_lane = bij_perm(g.bij, (uint32_t)pos);
+      src_row[threadIdx.x] = p_lane;
+    }
+    __syncthreads();
+  }
   // ---- observation element of this thread
   {
     const size_t row = row0 + (threadIdx.x >> g.o.qshift);
     const unsigned col = threadIdx.x & (Q - 1);
     if (row < KB) {
       size_t pos = g.o.row_base + row;
-      if (TAIL) {
+      if (TAIL && BIJ != 1) {
         const size_t k = pos / g.o.B, start = k * g.o.B;
         if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
       }
-      uint32_t p = g.o.perm[pos];
+      uint32_t p;
+      if (BIJ == 1) p = src_row[threadIdx.x >> g.o.qshift];
+      else if (BIJ == 2) p = bij_perm(g.bij, (uint32_t)pos);
+      else p = g.o.perm[pos];
       p = min(p, (uint32_t)(g.o.M - 1));
       const f32x4 *s = reinterpret_cast<const f32x4 *>(g.o.obs) + ((size_t)p * Q + col);
       f32x4 *d = reinterpret_cast<f32x4 *>(g.o.obs_out) + (row * Q + col);
@@ -267,7 +290,10 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
         const size_t k = pos / g.o.B, start = k * g.o.B;
         if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
       }
-      uint32_t p = g.s.perm[pos];
+      uint32_t p;
+      if (BIJ == 1) p = p_lane;
+      else if (BIJ == 2) p = bij_perm(g.bij, (uint32_t)pos);
+      else p = g.s.perm[pos];
       p = min(p, (uint32_t)(g.s.M - 1));
       const u32x2_t *rp = reinterpret_cast<const u32x2_t *>(g.s.rec + rec_static_idx(p));
       const u32x2_t qs = *rp, qd = *(rp + 8);
@@ -285,6 +311,13 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
     const double s1 = wave_sum(a), s2 = wave_sum(a * a);
     if (threadIdx.x == 0) g.s.partials[blockIdx.x] = make_double2(s1, s2);   // tile = the workgroup's rows (B % rpw == 0)
   }
+}
+
+// perm[j] = bij_perm(j) for j < M: the keyed bijection written out as an index array, for the gather kernels that
+// read one (rows wider than a workgroup, records beyond the Infinity Cache) and for ppo_xp_pass_perm_device / _host.
+__global__ __launch_bounds__(256) void bijection_perm_kernel(Bijection b, uint32_t *__restrict__ perm) {
+  const size_t j = (size_t)blockIdx.x * 256u + threadIdx.x;
+  if (j < b.M) perm[j] = bij_perm(b, (uint32_t)j);
 }
 
 // Fixed-order reduction of the tile partials of one minibatch by a 256-thread workgroup; the result is

@@ -171,6 +171,9 @@ struct ppo_xp {
   int pass_kind = 0;         // 0: scalar_gather_kernel + obs_gather_kernel, 1: fused_gather_kernel
   bool streaming = false;    // minibatches are gathered one at a time by pass_next into two alternating B-row slabs
   bool pass_streamed = false, pass_fusable = false;   // how the current pass was begun
+  // keyed-bijection pass (ppo_xp_pass_begin_bijection): perm(j) comes from `bij`; the index array h->perm is only
+  // written when a kernel that reads one runs (split path) or when the caller asks for it
+  Bijection bij{}; bool pass_bij = false, bij_inline = false, bij_perm_written = false;
   std::vector<uint32_t> perm_host;
   // Fisher-Yates of a coming pass drawn by a background thread (ppo_xp_shuffle_prefetch)
   std::thread pf_thread; std::vector<uint32_t> pf_perm; uint64_t pf_seed = 0; size_t pf_M = 0; bool pf_valid = false;
@@ -186,7 +189,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0, bij_mode = 1;
 };
 
 namespace {
@@ -571,6 +574,32 @@ int pass_finish_impl(ppo_xp *h) {
   return side_wait(h);
 }
 
+template <int BS>
+void launch_fused(ppo_xp *h, const FusedGatherArgs &f, dim3 grid, bool tail, int bij) {
+  if (bij == 1) {
+    if (tail) hipLaunchKernelGGL((fused_gather_kernel<BS, true, true, 1>), grid, dim3(BS), 0, h->stream, f);
+    else hipLaunchKernelGGL((fused_gather_kernel<BS, true, false, 1>), grid, dim3(BS), 0, h->stream, f);
+  } else if (bij == 2) {
+    if (tail) hipLaunchKernelGGL((fused_gather_kernel<BS, true, true, 2>), grid, dim3(BS), 0, h->stream, f);
+    else hipLaunchKernelGGL((fused_gather_kernel<BS, true, false, 2>), grid, dim3(BS), 0, h->stream, f);
+  } else {
+    if (tail) hipLaunchKernelGGL((fused_gather_kernel<BS, true, true, 0>), grid, dim3(BS), 0, h->stream, f);
+    else hipLaunchKernelGGL((fused_gather_kernel<BS, true, false, 0>), grid, dim3(BS), 0, h->stream, f);
+  }
+}
+
+// The keyed bijection of the current pass written out into h->perm (once per pass, on the handle's stream).
+int materialize_bijection(ppo_xp *h) {
+  if (!h->pass_bij || h->bij_perm_written) return 0;
+  const size_t M = h->bij.M;
+  if (M) {
+    hipLaunchKernelGGL(bijection_perm_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, h->stream, h->bij, h->perm);
+    if (int rc = launch_check("bijection_perm_kernel")) return rc;
+  }
+  h->bij_perm_written = true;
+  return 0;
+}
+
 // Gathers and standardises minibatches [k0, k0 + Kn) of the current pass into `o`.  Whole pass: k0 = 0, Kn = K;
 // streaming: one minibatch at a time.  Exchange modes (sharded ranks) only occur with the whole pass.
 int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
@@ -594,13 +623,10 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
       ProfScope ps(h, PPO_XP_K_GATHER);
       const bool tail = K * B != M;
       const dim3 grid((unsigned)blocks);
-      if (FBq == 256) {
-        if (tail) hipLaunchKernelGGL((fused_gather_kernel<256, true, true>), grid, dim3(256), 0, h->stream, f);
-        else hipLaunchKernelGGL((fused_gather_kernel<256, true, false>), grid, dim3(256), 0, h->stream, f);
-      } else {
-        if (tail) hipLaunchKernelGGL((fused_gather_kernel<512, true, true>), grid, dim3(512), 0, h->stream, f);
-        else hipLaunchKernelGGL((fused_gather_kernel<512, true, false>), grid, dim3(512), 0, h->stream, f);
-      }
+      const int bij = h->bij_inline ? (int)h->bij_mode : 0;
+      f.bij = h->bij;
+      if (FBq == 256) launch_fused<256>(h, f, grid, tail, bij);
+      else launch_fused<512>(h, f, grid, tail, bij);
       if (int rc = launch_check("fused_gather_kernel")) return rc;
     }
     // statistics: few tiles per minibatch -> every standardise workgroup folds them itself; many -> one
@@ -704,6 +730,13 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   }
   h->pass_kind = fusable ? 1 : 0;
   h->pass_fusable = fusable;
+  // keyed bijection: the fused kernel evaluates it in registers; the kernels that read an index array get it written
+  // out first (one small launch, inside the pass)
+  h->bij_inline = h->pass_bij && fusable && h->bij_mode != 0;
+  if (h->pass_bij && !h->bij_inline) {
+    if (int rc = materialize_bijection(h)) return rc;
+    h->perm_cur = h->perm;
+  }
   if (h->pass_streamed) return 0;            // ppo_xp_pass_next gathers minibatch k when it is asked for
   return gather_range(h, 0, K, pass_out_at(h, 0, 0));
 }
@@ -1051,7 +1084,7 @@ int ppo_xp_pass_begin(ppo_xp *h, size_t batch_size, const uint32_t *perm, uint64
     HIP_TRY(hipEventRecord(h->perm_ev, h->stream));
     h->perm_ev_used = true;
   }
-  h->perm_cur = h->perm;
+  h->perm_cur = h->perm; h->pass_bij = false;
   return pass_begin_impl(h, batch_size);
 }
 
@@ -1061,6 +1094,7 @@ int ppo_xp_pass_begin_device(ppo_xp *h, size_t batch_size, const uint32_t *perm_
   if (!perm_dev) return fail(PPO_XP_EINVAL, "pass_begin_device: perm is NULL");
   HIP_TRY(hipSetDevice(h->device));
   h->perm_cur = perm_dev;  // borrowed, not copied: see include/ppo_xp.h
+  h->pass_bij = false;
   return pass_begin_impl(h, batch_size);
 }
 
@@ -1079,7 +1113,18 @@ int ppo_xp_pass_begin_device_shuffle(ppo_xp *h, size_t batch_size, uint64_t seed
     int e = device_shuffle(seed, M, h->perm, h->shuffle_ws, h->shuffle_ws_bytes, h->stream);
     if (e != 0) return fail(PPO_XP_EIO, "device shuffle failed: %s", hipGetErrorString((hipError_t)e));
   }
-  h->perm_cur = h->perm;
+  h->perm_cur = h->perm; h->pass_bij = false;
+  return pass_begin_impl(h, batch_size);
+}
+
+int ppo_xp_pass_begin_bijection(ppo_xp *h, size_t batch_size, uint64_t seed) {
+  if (!h) return fail(PPO_XP_EINVAL, "pass_begin: handle is NULL");
+  if (batch_size == 0) return fail(PPO_XP_EINVAL, "pass_begin: batch_size 0 (the reference would iterate forever)");
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t M = buf_len(h) * h->N;
+  h->bij = bij_make(seed, M ? M : 1);
+  h->pass_bij = true; h->bij_perm_written = false;
+  h->perm_cur = nullptr;       // set to h->perm once the index array has been written
   return pass_begin_impl(h, batch_size);
 }
 
@@ -1205,13 +1250,22 @@ int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io) {
 
 int ppo_xp_pass_gather_kind(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_kind : -1; }
 size_t ppo_xp_pass_num_batches(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_K : 0; }
-const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *h) { return h ? h->perm_cur : nullptr; }
+const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *hc) {
+  ppo_xp *h = const_cast<ppo_xp *>(hc);
+  if (!h) return nullptr;
+  if (h->pass_bij && h->pass_active && !h->bij_perm_written) {     // inline pass: nobody has needed the array so far
+    if (hipSetDevice(h->device) != hipSuccess || materialize_bijection(h) != 0) return nullptr;
+    h->perm_cur = h->perm;
+  }
+  return h->perm_cur;
+}
 
 int ppo_xp_pass_perm_host(ppo_xp *h, uint32_t *out, size_t n) {
   if (!h || !out) return fail(PPO_XP_EINVAL, "pass_perm_host: NULL argument");
   if (!h->pass_active) return fail(PPO_XP_ESTATE, "pass_perm_host: no pass");
   if (n != h->pass_M) return fail(PPO_XP_EINVAL, "pass_perm_host: n = %zu, M = %zu", n, h->pass_M);
   HIP_TRY(hipSetDevice(h->device));
+  if (n && !ppo_xp_pass_perm_device(h)) return fail(PPO_XP_EIO, "pass_perm_host: the permutation could not be written out");
   if (n) HIP_TRY(hipMemcpyAsync(out, h->perm_cur, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   return 0;
@@ -1349,6 +1403,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "fused" && value >= -1 && value <= 1) h->fused = value;
   else if (n == "fused_block" && (value == 256 || value == 512)) h->fused_block = value;
   else if (n == "scalar_path" && (value == 0 || value == 1)) h->scalar_path = value;
+  else if (n == "bij_mode" && value >= 0 && value <= 2) h->bij_mode = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32)) h->gae_unroll = value;

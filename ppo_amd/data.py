@@ -108,17 +108,19 @@ class ExperienceBatcher:
         into_iter(seed=seed) that follows takes it (training.rs:204-205: one fresh permutation per pass)."""
         check(self._L.ppo_xp_shuffle_prefetch(self.buffer.handle, int(seed) & 0xFFFFFFFFFFFFFFFF))
 
-    def into_iter(self, seed: int | None = None, perm=None, device_shuffle: bool = False):
+    def into_iter(self, seed: int | None = None, perm=None, device_shuffle: bool = False, bijection: bool = False):
         """data.rs:91-102: a fresh permutation per pass.  perm: optional host u32 array or CUDA
         int32 tensor of M indices.  device_shuffle=True draws the permutation on the GPU (stable
-        argsort of SplitMix64 keys) instead of the host Fisher-Yates."""
-        return ExperienceBatcherIterator(self, seed, perm, device_shuffle)
+        argsort of SplitMix64 keys) instead of the host Fisher-Yates.  bijection=True: the permutation is a
+        keyed bijection of (seed, M) that the gather evaluates in registers (ppo_xp_pass_begin_bijection):
+        no index array is drawn, uploaded or read."""
+        return ExperienceBatcherIterator(self, seed, perm, device_shuffle, bijection)
 
 
 class ExperienceBatcherIterator:
     """data.rs:105-193."""
 
-    def __init__(self, batcher: ExperienceBatcher, seed=None, perm=None, device_shuffle=False):
+    def __init__(self, batcher: ExperienceBatcher, seed=None, perm=None, device_shuffle=False, bijection=False):
         self.batcher = batcher
         buf, L = batcher.buffer, batcher._L
         h = buf.handle
@@ -153,7 +155,9 @@ class ExperienceBatcherIterator:
                 seed = batcher._seed if batcher._seed is not None else next(ExperienceBatcher._seed_counter)
                 if batcher._seed is not None:
                     batcher._seed += 1  # a new permutation per pass (training.rs:204-205)
-            if device_shuffle:
+            if bijection:
+                check(L.ppo_xp_pass_begin_bijection(h, B, int(seed) & 0xFFFFFFFFFFFFFFFF))
+            elif device_shuffle:
                 check(L.ppo_xp_pass_begin_device_shuffle(h, B, int(seed) & 0xFFFFFFFFFFFFFFFF))
             else:
                 check(L.ppo_xp_pass_begin(h, B, None, int(seed) & 0xFFFFFFFFFFFFFFFF))

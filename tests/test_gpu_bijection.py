@@ -1,0 +1,124 @@
+"""ppo_xp_pass_begin_bijection on the GPU, through the C ABI: the permutation of a pass as a keyed bijection the
+gather kernels evaluate in registers (ppo_amd/csrc/bijection.h).  Replaces into_iter's shuffle (data.rs:91-102).
+
+  * indices bit-equal to the oracle's CPU twin for M in {1, 2, 1000, 2^23, a non-power-of-two >= 10^6};
+  * a bijection of 0..M at TGT size;
+  * minibatches bit-identical (rows, scalars AND standardised advantages: same kernels, same tiles) to
+    ppo_xp_pass_begin_device fed the written-out permutation, for every way the bijection is evaluated;
+  * the whole pass against the oracle at the usual bars (tests/test_gpu_parity.check_pass).
+The specific permutation is parity unpinned like every shuffle of this path (data.rs:94 is OS-seeded)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_gpu_fullsize import device_fill
+from test_gpu_parity import bits, both, check_pass
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def xp():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import ppo_amd
+    return ppo_amd
+
+
+@pytest.mark.parametrize("T,N,D", [(1, 1, 3), (1, 2, 4), (2, 1, 4), (10, 100, 8), (128, 65536, 4), (101, 10007, 4)])
+def test_indices_equal_the_cpu_twin(xp, oracle, T, N, D):
+    import torch
+    M = T * N
+    buf = xp.ExperienceBuffer(N, D, T)
+    z = torch.zeros
+    for t in range(T):      # contents do not matter here
+        buf.add_experience_device(z(N, D, device="cuda"), z(N, device="cuda"), z(N, dtype=torch.int64, device="cuda"),
+                                  z(N, device="cuda"), z(N, device="cuda"), z(N, device="cuda"))
+    buf.returns(np.zeros(N, np.uint8))
+    for seed in (0, 0x5EED, 2**64 - 1):
+        it = xp.ExperienceBatcher(buf, max(1, M // 4)).into_iter(seed=seed, bijection=True)
+        np.testing.assert_array_equal(it.perm(), oracle.bijection_perm(seed, M))
+    buf.close()
+
+
+@pytest.mark.parametrize("D,B,streaming", [(64, 4096, False), (64, 4000 - 32, False), (64, 4096, True), (32, 1024, False),
+                                           (256, 512, False), (6, 1000, False), (64, 77, False)])
+def test_pass_against_the_oracle(xp, oracle, D, B, streaming):
+    """Fused route (D = 32 / 64 / 256 with whole tiles), the two-kernel route (odd D, ragged B), overlapping tail windows,
+    streamed minibatches."""
+    T, N = 16, 500
+    g, o, r = both(xp, oracle, T, N, D, T, seed=3)
+    g.set_streaming(streaming)
+    check_pass(xp, oracle, g, o, r["last_dones"], B, seed=17, bijection=True)
+    g.close()
+
+
+def _collect(xp, buf, B, **kw):
+    out = []
+    it = xp.ExperienceBatcher(buf, B).into_iter(**kw)
+    for b in it:
+        out.append([t.clone() for t in (b.observations, b.actions, b.values, b.neglogps, b.returns, b.advantages)])
+    return it, out
+
+
+def _same(a, b):
+    import torch
+    assert len(a) == len(b)
+    for ma, mb in zip(a, b):
+        for x, y in zip(ma, mb):
+            assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x,
+                               y.view(torch.int32) if y.dtype == torch.float32 else y)
+
+
+@pytest.mark.parametrize("T,N,D,B", [(32, 1024, 64, 4096), (32, 1000, 64, 4000 - 64), (8, 300, 128, 160), (16, 512, 10, 1024)])
+def test_every_evaluation_mode_equals_the_array_pass(xp, T, N, D, B):
+    import torch
+    buf = xp.ExperienceBuffer(N, D, T)
+    r = device_fill(buf, T, N, D, 5)
+    buf.returns(r["last_dones"].cpu().numpy())
+    M = T * N
+    it, base = _collect(xp, buf, B, seed=21, bijection=True)
+    perm = torch.from_numpy(it.perm().astype(np.int32)).cuda()
+    _, want = _collect(xp, buf, B, perm=perm)
+    _same(base, want)
+    for mode in (0, 2, 1):
+        buf.set_tunable("bij_mode", mode)
+        _, got = _collect(xp, buf, B, seed=21, bijection=True)
+        _same(got, want)
+    buf.set_tunable("fused", 0)
+    _, got = _collect(xp, buf, B, seed=21, bijection=True)
+    _same(got, want)
+    buf.close()
+
+
+def test_tgt_size_bijection_and_rows(xp):
+    """TGT in full: the written-out bijection is a permutation of 0..M, the inline pass gathers exactly source[perm],
+    and standardises within 2e-6 of an fp64 evaluation."""
+    import torch
+    from ppo_amd import synth
+    T, N, D, B = synth.CONFIGS["TGT"]
+    M = T * N
+    buf = xp.ExperienceBuffer(N, D, T)
+    r = device_fill(buf, T, N, D, 77)
+    ret = buf.returns(r["last_dones"].cpu().numpy()).clone()
+    adv = buf.advantages().clone()
+    it = xp.ExperienceBatcher(buf, B).into_iter(seed=123456789, bijection=True)
+    assert xp._lib.load().ppo_xp_pass_gather_kind(buf.handle) == 1
+    batches = [[t.clone() for t in (b.observations, b.actions, b.values, b.neglogps, b.returns, b.advantages)] for b in it]
+    perm = xp.device_tensor(xp._lib.load().ppo_xp_pass_perm_device(buf.handle), (M,), torch.uint32, 0, buf).long()
+    assert torch.equal(torch.sort(perm).values, torch.arange(M, device="cuda"))
+    obs = r["obs"].reshape(M, D)
+    assert len(batches) == M // B
+    for k, (o, a, v, n, rt, ad) in enumerate(batches):
+        idx = perm[k * B:(k + 1) * B]
+        assert torch.equal(o, obs[idx])
+        assert torch.equal(a, r["actions"].reshape(-1)[idx])
+        assert torch.equal(v, r["values"].reshape(-1)[idx])
+        assert torch.equal(n, r["neglogps"].reshape(-1)[idx])
+        assert torch.equal(rt, ret[idx])
+        x = adv[idx].double()
+        ref = (x - x.mean()) / (x.std(unbiased=True) + 1e-8)
+        assert (ad.double() - ref).abs().max().item() < 2e-6
+    buf.close()
+    torch.cuda.empty_cache()

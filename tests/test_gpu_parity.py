@@ -60,7 +60,7 @@ def both(xp, oracle, T, N, D, cap, seed, p_done=0.05, steps=None, bulk=False):
     return g, o, r
 
 
-def check_pass(xp, oracle, g, o, last_dones, B, seed=None, perm=None, algo=0, exact_returns=True):
+def check_pass(xp, oracle, g, o, last_dones, B, seed=None, perm=None, algo=0, exact_returns=True, bijection=False):
     """Runs returns + one shuffled pass on both sides and compares everything."""
     N, D = g.num_envs, g.obs_size
     ret_g = g.returns(last_dones, algo=algo).cpu().numpy()
@@ -81,7 +81,7 @@ def check_pass(xp, oracle, g, o, last_dones, B, seed=None, perm=None, algo=0, ex
     M = len(o) * N
     batcher = xp.ExperienceBatcher.new(*g.training_views(), g.returns(last_dones, algo=algo), B)
     assert len(batcher) == M
-    it = batcher.into_iter(seed=seed, perm=perm)
+    it = batcher.into_iter(seed=seed, perm=perm, bijection=bijection)
     batches = list(it)
     windows = oracle.batch_windows(M, B)
     assert len(batches) == len(windows) == oracle.num_batches(M, B)
@@ -90,6 +90,8 @@ def check_pass(xp, oracle, g, o, last_dones, B, seed=None, perm=None, algo=0, ex
     p = it.perm()
     if perm is not None:
         np.testing.assert_array_equal(p, np.asarray(perm, np.uint32))
+    elif bijection:
+        np.testing.assert_array_equal(p, oracle.bijection_perm(seed, M))   # the keyed bijection's CPU twin
     else:
         np.testing.assert_array_equal(p, oracle.shuffle(seed, M))   # bit-exact permutation indices
     stats = it.stats()
