@@ -36,8 +36,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/
 ACTION_BYTES, INDEX_BYTES = 8, 4
 
 
-def alg_bytes_total(D):      # B_alg = 8D + 2A + I + 56
-    return 8 * D + 2 * ACTION_BYTES + INDEX_BYTES + 56
+def alg_bytes_total(D, index_bytes=INDEX_BYTES):      # B_alg = 8D + 2A + I + 56
+    return 8 * D + 2 * ACTION_BYTES + index_bytes + 56
 
 
 # How B_alg splits over the kernels (DESIGN.md "Kernels"): GAE 20 | scalar gather: index I +
@@ -47,8 +47,8 @@ def alg_bytes_obs_gather(D):
     return 8 * D
 
 
-def alg_bytes_fused_gather(D):   # rows + the scalar gather's share: index I, actions 2A, v/nlp/ret 24, advantage read + raw write 8
-    return 8 * D + INDEX_BYTES + 2 * ACTION_BYTES + 24 + 8
+def alg_bytes_fused_gather(D, index_bytes=INDEX_BYTES):   # rows + the scalar gather's share: index I, actions 2A, v/nlp/ret 24, advantage read + raw write 8
+    return 8 * D + index_bytes + 2 * ACTION_BYTES + 24 + 8
 
 
 def log(*a):
@@ -158,7 +158,7 @@ class Ctx:
         self.args, self.rank, self.world, self.local_rank, self.dev, self.multi = args, rank, world, local_rank, dev, multi
 
 
-def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tunables=()):
+def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tunables=(), exchange=None):
     """returns() + one shuffled pass per step on config `cfg`; every rank owns the config's envs (C5: its
     share).  Returns (result dict, M, D, K, gae_only) — the dict is complete on rank 0."""
     import torch
@@ -167,6 +167,7 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     from ppo_amd import _lib, sharded, synth
 
     args, rank, world, dev = ctx.args, ctx.rank, ctx.world, ctx.dev
+    exchange = exchange or args.exchange
     T, N, D, B = synth.CONFIGS[cfg]           # per-GPU shard: weak scaling, every rank owns N envs
     if cfg == "C5":                           # N/G envs and B/G rows per GPU
         assert N % world == 0 and B % world == 0
@@ -220,8 +221,13 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     ld_p = last_dones.ctypes.data_as(C.c_void_p)
     _lib.check(L.ppo_xp_returns(h, ld_p, N, algo, None))
     perms, t_perm, perm_kind = [], 0.0, "none"
-    if not gae_only:
-        host_fy = M <= (1 << 25)
+    bijection = args.perm == "bijection"
+    if not gae_only and bijection:
+        # the permutation of every pass is a keyed bijection of (seed, M) evaluated inside the gather: a fresh one per
+        # step, generated INSIDE the timed region (nothing is drawn, uploaded or read beforehand)
+        perm_kind = "inline keyed bijection"
+    elif not gae_only:
+        host_fy = args.perm == "host" and M <= (1 << 25)
         perm_kind = "host Fisher-Yates (rand 0.8.5 / ChaCha12)" if host_fy else "device generator (SplitMix64 keys + radix sort)"
         t0 = time.perf_counter()
         for i in range(2):
@@ -237,8 +243,9 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
 
     # ---- exchange of the per-minibatch sums across ranks (the only cross-GPU step) -----------
     comm, sb = None, None
+    rccl_ranks = (world if (ctx.multi and args.backend == "nccl") else 0)   # ranks of the RCCL communicator the exchange runs on
     if exch:
-        if args.exchange == "rccl":
+        if exchange == "rccl":
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
                 raw = (C.c_char * 128)()
@@ -250,18 +257,31 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
             comm = C.c_void_p()
             _lib.check(L.ppo_xp_rccl_comm_init(C.byref(comm), raw, rank, world))
             buf.set_exchange(1, comm.value)
+            nr = C.c_int(0)
+            _lib.check(L.ppo_xp_rccl_comm_count(comm, C.byref(nr)))
+            rccl_ranks = nr.value
         else:
             sb = sharded.ShardedBatcher(buf, B * world)      # global batch = world x local batch; sets exchange mode 2
 
     bv = _lib.BatchView()
+    step_no = [0]
+    xev = None          # torch events around the caller-side all-reduce (breakdown steps only)
 
     def step(i):
         _lib.check(L.ppo_xp_returns(h, ld_p, N, algo, None))
         if gae_only:
             return
-        _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perms[i & 1].data_ptr())))
+        if bijection:
+            _lib.check(L.ppo_xp_pass_begin_bijection(h, B, (seed << 20) + step_no[0]))
+            step_no[0] += 1
+        else:
+            _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perms[i & 1].data_ptr())))
         if sb is not None:
+            if xev is not None:
+                xev[0].record()
             sb.exchange()                                    # ONE all-reduce of 3K doubles, then standardise
+            if xev is not None:
+                xev[1].record()
         n = 0
         while L.ppo_xp_pass_next(h, C.byref(bv)) == 0:
             n += 1
@@ -294,12 +314,24 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     dt = time.perf_counter() - t0
     prof = buf.prof_collect()
     prof_all = {}
+    exch_us = None
     if breakdown:   # per-kernel breakdown: a few more steps with every kernel bracketed, outside the timed region
         buf.prof_enable(True)
+        xt = []
         for i in range(5):
+            if sb is not None:
+                xev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             step(i)
+            if xev is not None:
+                torch.cuda.synchronize()
+                xt.append(xev[0].elapsed_time(xev[1]) * 1e3)
+                xev = None
         barrier()
         prof_all = buf.prof_collect()
+        if xt:
+            exch_us = float(np.median(xt))        # all-reduce + the standardise launch behind it, on the pass's stream
+        elif prof_all.get("exchange", (0, 0))[1]:
+            exch_us = prof_all["exchange"][0] / prof_all["exchange"][1] * 1e3
     buf.prof_enable(False)
 
     extra = {}
@@ -312,8 +344,12 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         extra["assoc_bound_stated"] = 1e-5
         del r1, r2
 
+    rank_ms = [dt / steps * 1e3]
     if ctx.multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        every = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(every, tt)
+        rank_ms = [float(t.item()) / steps * 1e3 for t in every]
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -330,8 +366,10 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     value = world * M * steps / dt
     g_ms, g_n = prof[dom]
     g_avg_s = g_ms / max(g_n, 1) * 1e-3
-    dom_bytes = 20 if gae_only else alg_bytes_fused_gather(D) if fused else alg_bytes_obs_gather(D)   # per transition, SURVEY.md 8(d)
-    step_bytes = 20 if gae_only else alg_bytes_total(D)
+    # I = 0 when no index is read: the fused gather evaluates the keyed bijection in registers
+    ib = 0 if (bijection and fused) else INDEX_BYTES
+    dom_bytes = 20 if gae_only else alg_bytes_fused_gather(D, ib) if fused else alg_bytes_obs_gather(D)   # per transition, SURVEY.md 8(d)
+    step_bytes = 20 if gae_only else alg_bytes_total(D, ib)
     achieved = M * dom_bytes / g_avg_s / 1e9 if g_n else 0.0
     kern = {k: {"avg_us": v[0] / v[1] * 1e3, "launches": v[1]} for k, v in prof_all.items() if v[1]}
     scan = "associative (chunked)" if algo & 1 else "sequential"
@@ -343,7 +381,7 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         "scaling": "strong" if cfg == "C5" else "weak",
         "config": {"workload": workload, "global_envs": world * N,
                    "parallelism": f"env-sharded x{world}" if ctx.multi else "single GPU",
-                   "exchange": ((args.exchange + "/" + args.backend) if ctx.multi else "none"),
+                   "exchange": ((exchange + "/" + args.backend) if ctx.multi else "none"),
                    "minibatches": "streamed one at a time into two slots" if buf.streaming else "all K gathered by one pass launch"},
         "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
         "alg_bytes_per_transition": step_bytes,
@@ -352,7 +390,14 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes_per_launch": M * dom_bytes, "avg_launch_us": g_avg_s * 1e6, "launches_timed": g_n},
         "kernels_untimed_breakdown": kern,
-        "off_metric": {"insert_s": t_insert, "perm_s": t_perm, "perm_kind": perm_kind},
+        "off_metric": {"insert_s": t_insert, "perm_s": t_perm,
+                       "perm_note": "0: the permutation is generated inside the timed step" if bijection else "drawn before the timed region"},
+        "perm_kind": (perm_kind if not (bijection and not fused and not gae_only) else
+                      "keyed bijection, written out as an index array by one launch inside the timed step (split gather kernels read an array)"),
+        "index_bytes": ib,
+        "rccl_ranks": rccl_ranks,
+        "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
+        "exchange_exposed_us": exch_us,
     }
     res.update(extra)
     return res, (T, N, D, K, gae_only)
@@ -392,6 +437,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other configs that a default run reports under 'also'")
     ap.add_argument("--exchange", default=os.environ.get("PPO_XP_EXCHANGE", "torch"), choices=["torch", "rccl"])
+    ap.add_argument("--perm", default="bijection", choices=["bijection", "host", "device_sort"],
+                    help="bijection: keyed bijection evaluated inside the gather, a fresh one per step inside the timed region (default); "
+                         "host: rand-0.8.5 Fisher-Yates drawn before the timed region (reference-faithful); device_sort: SplitMix64 keys + radix sort")
     ap.add_argument("--backend", default=os.environ.get("PPO_XP_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo = rehearsal of the multi-rank control flow with all ranks on one GPU")
     ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
@@ -472,12 +520,18 @@ def main():
         also = {}
         # one GPU: configs[1] C2, configs[2] C3, configs[3] C4 (GAE only, K2 + its error against K1) and C5 whole on
         # this GPU (= the per-GPU shard of a 1-rank job); N GPUs: C5 split over the ranks (strong scaling)
-        todo = [("C5", 10, 3)] if world > 1 else [("C3", 12, 3), ("C5", 10, 3), ("C2", 200, 20), ("C4", 100, 10)]
-        for cfg, st, wu in todo:
+        todo = [("C5", 10, 3, None)] if world > 1 else [("C3", 12, 3, None), ("C5", 10, 3, None), ("C2", 200, 20, None), ("C4", 100, 10, None)]
+        if multi:
+            # the headline ran with --exchange (default: the caller all-reduces through torch.distributed); measure TGT again with
+            # the other one, so that the library's own ncclAllReduce (exchange mode 1) executes whenever there are ranks
+            other = "rccl" if args.exchange == "torch" else "torch"
+            if not (other == "rccl" and args.backend != "nccl"):
+                todo.insert(0, ("TGT", args.steps, args.warmup, other))
+        for cfg, st, wu, xch in todo:
             try:
-                r2, _ = measure(ctx, cfg, st, wu, events=False, breakdown=(cfg != "C2"))
+                r2, _ = measure(ctx, cfg, st, wu, events=False, breakdown=(cfg != "C2"), exchange=xch)
                 r2.pop("roofline", None)
-                also[cfg] = r2
+                also[cfg if xch is None else f"{cfg}_exchange_{xch}"] = r2
             except Exception as e:
                 if world > 1:           # a rank that gives up alone would leave the others inside a collective
                     raise

@@ -278,6 +278,7 @@ int ppo_xp_pass_finish(ppo_xp *h);
  * ncclCommDestroy so that a host without RCCL bindings can still build the communicator). */
 int ppo_xp_rccl_unique_id(void *out128);
 int ppo_xp_rccl_comm_init(void **comm_out, const void *unique_id128, int rank, int world);
+int ppo_xp_rccl_comm_count(void *comm, int *ranks_out); /* ncclCommCount: ranks the communicator really has */
 int ppo_xp_rccl_comm_destroy(void *comm);
 
 /* ---- reward normalisation, the step before add_experience (next row) ---- */
@@ -318,7 +319,8 @@ int ppo_xp_device(const ppo_xp *h);
  * event pair is recorded around every launch of the selected kernels; collect synchronises, adds
  * up elapsed ms and launch counts per kernel id and resets. */
 enum { PPO_XP_K_GAE = 0, PPO_XP_K_GAE_SUMMARY, PPO_XP_K_GAE_CARRY, PPO_XP_K_PACK, PPO_XP_K_GATHER,
-       PPO_XP_K_FINALIZE, PPO_XP_K_NORMALIZE, PPO_XP_K_SCALARS, PPO_XP_K_COUNT };
+       PPO_XP_K_FINALIZE, PPO_XP_K_NORMALIZE, PPO_XP_K_SCALARS, PPO_XP_K_EXCHANGE /* the library's own ncclAllReduce */,
+       PPO_XP_K_COUNT };
 int ppo_xp_prof_enable(ppo_xp *h, int enable);
 int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launches_out /*[K_COUNT]*/);
 const char *ppo_xp_kernel_name(int kernel_id);

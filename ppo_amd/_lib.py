@@ -14,9 +14,9 @@ LIB_PATH = os.path.join(_HERE, "libppo_xp.so")
 OK, EINVAL, ENOMEM, EIO, ENODEV, ESTATE = 0, -22, -12, -5, -19, -1
 GAE_SEQUENTIAL, GAE_ASSOC, GAE_NO_PACK = 0, 1, 0x100
 K_NAMES = ("gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records", "gather", "finalize_stats", "normalize",
-           "scalar_gather")
-K_GAE, K_GAE_SUMMARY, K_GAE_CARRY, K_PACK, K_GATHER, K_FINALIZE, K_NORMALIZE, K_SCALARS = range(8)
-K_COUNT = 8
+           "scalar_gather", "exchange")
+K_GAE, K_GAE_SUMMARY, K_GAE_CARRY, K_PACK, K_GATHER, K_FINALIZE, K_NORMALIZE, K_SCALARS, K_EXCHANGE = range(9)
+K_COUNT = 9
 
 
 def gae_chunk(length: int) -> int:
@@ -94,6 +94,7 @@ SYMBOLS = {
     "ppo_xp_pass_finish": (_i, [_vp]),
     "ppo_xp_rccl_unique_id": (_i, [_vp]),
     "ppo_xp_rccl_comm_init": (_i, [C.POINTER(_vp), _vp, _i, _i]),
+    "ppo_xp_rccl_comm_count": (_i, [_vp, C.POINTER(_i)]),
     "ppo_xp_rccl_comm_destroy": (_i, [_vp]),
     "ppo_xp_rnorm_create": (_i, [C.POINTER(_vp), _i, _sz, _f, _f, _f]),
     "ppo_xp_rnorm_destroy": (None, [_vp]),

@@ -61,6 +61,7 @@ struct RcclApi {
   int (*GetUniqueId)(RcclUniqueId *) = nullptr;
   int (*CommInitRank)(void **, int, RcclUniqueId, int) = nullptr;
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;
   int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
 };
@@ -77,9 +78,10 @@ int rccl_load() {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(lib, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(lib, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(lib, "ncclCommDestroy");
+  a.CommCount = (decltype(a.CommCount))dlsym(lib, "ncclCommCount");
   a.AllReduce = (decltype(a.AllReduce))dlsym(lib, "ncclAllReduce");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(lib, "ncclGetErrorString");
-  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.GetErrorString)
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.CommCount || !a.AllReduce || !a.GetErrorString)
     return fail(PPO_XP_EIO, "librccl lacks an expected ncclXxx symbol");
   g_rccl = a;
   return 0;
@@ -600,6 +602,15 @@ int materialize_bijection(ppo_xp *h) {
   return 0;
 }
 
+// The one cross-GPU step of the path: all-reduce(sum) of the K (count, sum, sum of squares) triples, in place, on the
+// handle's stream (exchange mode 1: the library's own RCCL call).
+int exchange_sums(ppo_xp *h, size_t K) {
+  ProfScope ps(h, PPO_XP_K_EXCHANGE);
+  const int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+  return 0;
+}
+
 // Gathers and standardises minibatches [k0, k0 + Kn) of the current pass into `o`.  Whole pass: k0 = 0, Kn = K;
 // streaming: one minibatch at a time.  Exchange modes (sharded ranks) only occur with the whole pass.
 int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
@@ -650,8 +661,7 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
       if (int rc = launch_check("finalize_stats_kernel")) return rc;
     }
     if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
-    int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
-    if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+    if (int rc = exchange_sums(h, K)) return rc;
     return pass_finish_impl(h);
   }
   // scalar streams + statistics first (the records were just written by the GAE kernel and are
@@ -692,8 +702,7 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
   if (!overlap)
     if (int rc = launch_obs_gather(h, K, B, M, k0, Kn, o.obs)) return rc;
   if (h->xmode == 2) { h->pass_pending_finish = true; return 0; }
-  int e = g_rccl.AllReduce(h->sums, h->sums, 3 * K, kNcclFloat64, kNcclSum, h->comm, h->stream);
-  if (e != 0) return fail(PPO_XP_EIO, "ncclAllReduce failed: %s", g_rccl.GetErrorString(e));
+  if (int rc = exchange_sums(h, K)) return rc;
   return pass_finish_impl(h);
 }
 
@@ -761,7 +770,7 @@ const char *ppo_xp_version(void) { return "ppo_xp 0.1 (gfx950)"; }
 
 const char *ppo_xp_kernel_name(int k) {
   static const char *names[PPO_XP_K_COUNT] = {"gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records",
-                                              "gather", "finalize_stats", "normalize", "scalar_gather"};
+                                              "gather", "finalize_stats", "normalize", "scalar_gather", "exchange"};
   return (k >= 0 && k < PPO_XP_K_COUNT) ? names[k] : "?";
 }
 
@@ -1336,6 +1345,14 @@ int ppo_xp_rccl_comm_init(void **comm_out, const void *unique_id128, int rank, i
   int e = g_rccl.CommInitRank(&comm, world, id, rank);
   if (e != 0) return fail(PPO_XP_EIO, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(e));
   *comm_out = comm;
+  return 0;
+}
+
+int ppo_xp_rccl_comm_count(void *comm, int *ranks_out) {
+  if (!comm || !ranks_out) return fail(PPO_XP_EINVAL, "rccl_comm_count: NULL");
+  if (int rc = rccl_load()) return rc;
+  int e = g_rccl.CommCount(comm, ranks_out);
+  if (e != 0) return fail(PPO_XP_EIO, "ncclCommCount failed: %s", g_rccl.GetErrorString(e));
   return 0;
 }
 

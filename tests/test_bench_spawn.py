@@ -73,3 +73,43 @@ def test_parent_spawns_before_importing_torch():
     import torch
     if not torch.cuda.is_available():
         assert p.returncode != 0 and p.stdout.strip() == ""
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_rank_rehearsal_line_has_the_multi_gpu_keys():
+    """`python bench.py --gpus 2 --backend gloo`: two ranks share the one GPU (RCCL needs one GPU per rank, so the
+    in-library ncclAllReduce leg is skipped under gloo); the line must carry what a scaling run is judged by."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "C2",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["exchange"] == "torch/gloo"
+    assert out["rccl_ranks"] == 0                      # gloo rehearsal: no RCCL communicator exists
+    assert out["rank_ms_per_step"]["min"] <= out["rank_ms_per_step"]["max"] == pytest.approx(out["ms_per_step"])
+    assert out["exchange_exposed_us"] is not None and out["exchange_exposed_us"] > 0
+    assert out["perm_kind"] == "inline keyed bijection" and out["index_bytes"] == 0
+    assert out["alg_bytes_per_transition"] == 584
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_line_runs_both_exchanges():
+    """PPO_XP_FORCE_PG=1: the multi-rank control flow with ONE rank over RCCL - the headline under the caller-side
+    all-reduce and TGT again under the library's own ncclAllReduce (`also.TGT_exchange_rccl`)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", PPO_XP_FORCE_PG="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][0])
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["config"]["exchange"] == "torch/nccl"
+    other = out["also"]["TGT_exchange_rccl"]
+    assert other["rccl_ranks"] == 1 and other["config"]["exchange"] == "rccl/nccl"
+    assert other["exchange_exposed_us"] is not None
