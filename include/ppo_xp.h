@@ -334,7 +334,7 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),
  * "fused_block" 256/512 (its workgroup size), "bij_mode" 0/1/2 (keyed-bijection passes: 0 = always write the index
  * array out first, 1 = one evaluation per output row handed to the row's threads through LDS, 2 = every thread evaluates
- * its own), "scalar_path" 0/1 (1: the partitioned scalar path of kernels_partition.h),
+ * its own),
  * "overlap" 0/1 (1: with the two-kernel path, the observation rows are gathered on a side stream of the handle while
  * the scalar streams, statistics and standardisation run on its own; joined before the pass is handed out).
  * Unknown names or values => PPO_XP_EINVAL. */

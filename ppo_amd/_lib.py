@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libppo_xp.so")
+# PPO_XP_LIB: another build of the same ABI (tests load libppo_xp_experiments.so this way); default = the product library
+LIB_PATH = os.environ.get("PPO_XP_LIB") or os.path.join(_HERE, "libppo_xp.so")
 
 OK, EINVAL, ENOMEM, EIO, ENODEV, ESTATE = 0, -22, -12, -5, -19, -1
 GAE_SEQUENTIAL, GAE_ASSOC, GAE_NO_PACK = 0, 1, 0x100

@@ -89,6 +89,8 @@ struct ObsGatherArgs {
   float *obs_out;          // [K*B, D]
   size_t M, B, total;      // total = Kn*B*Q vector elements to move (Kn minibatches in this launch)
   size_t row_base;         // first output row of the launch in the pass (k0*B; 0 unless minibatches are streamed one by one)
+  size_t tail_from, tail_shift;   // TAIL: positions >= tail_from = (K-1)*B belong to the overlapping last window, which
+                                  // starts at M - B (data.rs:121-122): they read position pos - tail_shift, tail_shift = K*B - M
   unsigned Q, qshift;      // Q = D / V vector elements per row; qshift = log2(Q) when POW2
   unsigned nblocks, xcd;   // grid size; xcd: 0 = identity, 1 = 8x8 chunk remap, 2 = one contiguous eighth per XCD
 };
@@ -123,10 +125,7 @@ __device__ __forceinline__ void obs_gather_body(const ObsGatherArgs &g, size_t b
   if (POW2) { row = e >> g.qshift; col = (unsigned)e & (g.Q - 1); }
   else { row = e / g.Q; col = (unsigned)(e - row * g.Q); }
   size_t pos = g.row_base + row;                              // position in the permutation
-  if (TAIL) {                                                 // data.rs:121-122
-    const size_t k = pos / g.B, start = k * g.B;
-    if (start + g.B > g.M) pos = pos - start + (g.M - g.B);
-  }
+  if (TAIL && pos >= g.tail_from) pos -= g.tail_shift;        // data.rs:121-122
   uint32_t p = g.perm[pos];
   p = min(p, (uint32_t)(g.M - 1));                            // a bad index can never fault
   const vec *s = reinterpret_cast<const vec *>(g.obs) + ((size_t)p * g.Q + col);
@@ -249,10 +248,7 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
   if (BIJ == 1) {
     if (threadIdx.x < rpw && row0 + threadIdx.x < KB) {
       size_t pos = g.o.row_base + row0 + threadIdx.x;
-      if (TAIL) {
-        const size_t k = pos / g.o.B, start = k * g.o.B;
-        if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
-      }
+      if (TAIL && pos >= g.o.tail_from) pos -= g.o.tail_shift;   // data.rs:121-122
       p_lane = bij_perm(g.bij, (uint32_t)pos);
       src_row[threadIdx.x] = p_lane;
     }
@@ -264,10 +260,7 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
     const unsigned col = threadIdx.x & (Q - 1);
     if (row < KB) {
       size_t pos = g.o.row_base + row;
-      if (TAIL && BIJ != 1) {
-        const size_t k = pos / g.o.B, start = k * g.o.B;
-        if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
-      }
+      if (TAIL && BIJ != 1 && pos >= g.o.tail_from) pos -= g.o.tail_shift;
       uint32_t p;
       if (BIJ == 1) p = src_row[threadIdx.x >> g.o.qshift];
       else if (BIJ == 2) p = bij_perm(g.bij, (uint32_t)pos);
@@ -286,10 +279,7 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
     float adv = 0.f;
     if (valid) {
       size_t pos = g.o.row_base + row;
-      if (TAIL) {
-        const size_t k = pos / g.o.B, start = k * g.o.B;
-        if (start + g.o.B > g.o.M) pos = pos - start + (g.o.M - g.o.B);
-      }
+      if (TAIL && pos >= g.o.tail_from) pos -= g.o.tail_shift;   // data.rs:121-122
       uint32_t p;
       if (BIJ == 1) p = p_lane;
       else if (BIJ == 2) p = bij_perm(g.bij, (uint32_t)pos);

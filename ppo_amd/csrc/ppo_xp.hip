@@ -20,7 +20,9 @@
 
 #include "kernels_gae.h"
 #include "kernels_gather.h"
+#ifdef PPO_XP_EXPERIMENTS   // losing experiments kept as evidence: built only into libppo_xp_experiments.so (make experiments)
 #include "kernels_partition.h"
+#endif
 #include "shuffle.h"
 #include "device_shuffle.h"
 #include "errors.h"
@@ -180,7 +182,9 @@ struct ppo_xp {
   // Fisher-Yates of a coming pass drawn by a background thread (ppo_xp_shuffle_prefetch)
   std::thread pf_thread; std::vector<uint32_t> pf_perm; uint64_t pf_seed = 0; size_t pf_M = 0; bool pf_valid = false;
   void *shuffle_ws = nullptr; size_t shuffle_ws_bytes = 0;   // device permutation generator workspace
+#ifdef PPO_XP_EXPERIMENTS
   void *part_ws = nullptr; size_t part_ws_bytes = 0;         // partitioned scalar path: counters, pairs, entries
+#endif
   double *moments = nullptr;                                  // [kMomentBlocks][4] partials of explained_variance
   // exchange
   int xmode = 0; void *comm = nullptr;
@@ -404,6 +408,7 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M, size_t k0, size_t
   const int V = (D % 4 == 0) ? 4 : (D % 2 == 0) ? 2 : 1;
   ObsGatherArgs g{};
   g.obs = h->obs; g.perm = h->perm_cur; g.obs_out = obs_out; g.M = M; g.B = B; g.row_base = k0 * B;
+  g.tail_from = (K - 1) * B; g.tail_shift = K * B - M;
   g.Q = D / V;
   g.total = Kn * B * g.Q;
   const bool pow2 = (g.Q & (g.Q - 1)) == 0;
@@ -427,6 +432,7 @@ int launch_obs_gather(ppo_xp *h, size_t K, size_t B, size_t M, size_t k0, size_t
   return launch_check("obs_gather_kernel");
 }
 
+#ifdef PPO_XP_EXPERIMENTS
 // The scalar streams through the partitioned path (kernels_partition.h): six streaming launches instead of one
 // kernel that fetches a 128-byte line per record.  Same outputs, same tile partials.
 int launch_partitioned_scalars(ppo_xp *h, const ScalarGatherArgs &g, size_t K, size_t B, size_t M) {
@@ -469,6 +475,7 @@ int launch_partitioned_scalars(ppo_xp *h, const ScalarGatherArgs &g, size_t K, s
                      g.tiles_per_mb);
   return launch_check("partitioned scalar path");
 }
+#endif
 
 int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   // sized for this batch size at FULL capacity, so that a pass over a partly filled ring followed by
@@ -624,6 +631,7 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
     f.rpw = rpw;
     f.o.obs = h->obs; f.o.perm = h->perm_cur; f.o.obs_out = o.obs; f.o.M = M; f.o.B = B; f.o.Q = Dq; f.o.row_base = k0 * B;
     f.o.total = Kn * B * Dq; f.o.qshift = 0;
+    f.o.tail_from = (K - 1) * B; f.o.tail_shift = K * B - M;
     while ((1u << f.o.qshift) < Dq) ++f.o.qshift;
     f.s.rec = h->rec; f.s.actions = h->actions; f.s.perm = h->perm_cur; f.s.act_out = o.act;
     f.s.val_out = o.val; f.s.nlp_out = o.nlp; f.s.ret_out = o.ret; f.s.adv_out = o.adv;
@@ -671,13 +679,20 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
   g.val_out = o.val; g.nlp_out = o.nlp; g.ret_out = o.ret; g.adv_out = o.adv;
   g.partials = h->partials; g.M = M; g.B = B; g.tiles_per_mb = (unsigned)((B + 255) / 256); g.k0 = (unsigned)k0;
   g.rec_nt = (int)h->rec_nt; g.out_nt = (int)h->out_nt;
+#ifdef PPO_XP_EXPERIMENTS
   const bool partitioned = whole && h->scalar_path == 1 && K * B == M && M >= kPartChunk &&
                            ((M + (size_t(1) << kSrcShift) - 1) >> kSrcShift) <= kMaxBins && ((M + (size_t(1) << kDstShift) - 1) >> kDstShift) <= kMaxBins;
+#else
+  const bool partitioned = false;
+  (void)whole;
+#endif
   const bool overlap = h->overlap != 0;
   if (overlap)
     if (int rc = launch_obs_side(h, K, B, M, k0, Kn, o.obs)) return rc;
   if (partitioned) {
+#ifdef PPO_XP_EXPERIMENTS
     if (int rc = launch_partitioned_scalars(h, g, K, B, M)) return rc;
+#endif
   } else {
     ProfScope ps(h, PPO_XP_K_SCALARS);
     hipLaunchKernelGGL(scalar_gather_kernel, dim3((unsigned)(Kn * g.tiles_per_mb)), dim3(256), 0, h->stream, g);
@@ -766,7 +781,11 @@ int pass_begin_impl(ppo_xp *h, size_t B) {
 extern "C" {
 
 const char *ppo_xp_last_error(void) { return g_err.c_str(); }
+#ifdef PPO_XP_EXPERIMENTS
+const char *ppo_xp_version(void) { return "ppo_xp 0.1 (gfx950) +experiments"; }
+#else
 const char *ppo_xp_version(void) { return "ppo_xp 0.1 (gfx950)"; }
+#endif
 
 const char *ppo_xp_kernel_name(int k) {
   static const char *names[PPO_XP_K_COUNT] = {"gae_scan", "gae_chunk_summary", "gae_carry_scan", "pack_records",
@@ -854,7 +873,9 @@ void ppo_xp_destroy(ppo_xp *h) {
   dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
   dev_free(h->moments);
   if (h->shuffle_ws) { (void)hipFree(h->shuffle_ws); h->shuffle_ws = nullptr; }
+#ifdef PPO_XP_EXPERIMENTS
   if (h->part_ws) { (void)hipFree(h->part_ws); h->part_ws = nullptr; }
+#endif
   if (h->last_dones_pin) (void)hipHostFree(h->last_dones_pin);
   if (h->stage_pin) (void)hipHostFree(h->stage_pin);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
@@ -1419,7 +1440,9 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "gae_flat" && (value == 0 || value == 1)) h->gae_flat = value;
   else if (n == "fused" && value >= -1 && value <= 1) h->fused = value;
   else if (n == "fused_block" && (value == 256 || value == 512)) h->fused_block = value;
+#ifdef PPO_XP_EXPERIMENTS
   else if (n == "scalar_path" && (value == 0 || value == 1)) h->scalar_path = value;
+#endif
   else if (n == "bij_mode" && value >= 0 && value <= 2) h->bij_mode = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;

@@ -44,16 +44,17 @@ def test_random_configurations(xp, oracle, chunk):
         buf.set_tunable("fold_tiles", int(g.choice([0, 256])))
         buf.set_tunable("fused", int(g.choice([-1, 0, 1])))
         buf.set_tunable("fused_block", int(g.choice([256, 512])))
-        buf.set_tunable("scalar_path", int(g.choice([0, 1])))
+        buf.set_tunable("bij_mode", int(g.choice([0, 1, 2])))
         buf.set_tunable("overlap", int(g.choice([0, 1])))
         M = len(orc) * N
         perm = None
         seed = int(g.integers(1 << 62))
-        if g.random() < 0.3:
+        how = g.random()
+        if how < 0.3:
             perm, seed = g.permutation(M).astype(np.uint32), None
         try:
             check_pass(xp, oracle, buf, orc, r["last_dones"], B, seed=seed, perm=perm, algo=algo,
-                       exact_returns=algo_kind != 2)
+                       exact_returns=algo_kind != 2, bijection=how > 0.65)
         except AssertionError as e:
             raise AssertionError(f"case {chunk}/{i}: cap={cap} steps={steps} N={N} D={D} B={B} algo={algo:#x}: {e}") from e
         finally:

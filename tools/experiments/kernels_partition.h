@@ -22,8 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "kernels_gae.h"
-#include "kernels_gather.h"
+#include "../../ppo_amd/csrc/kernels_gae.h"
+#include "../../ppo_amd/csrc/kernels_gather.h"
 
 namespace ppoxp {
 
