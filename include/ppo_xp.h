@@ -160,17 +160,19 @@ size_t ppo_xp_last_values_idx(const ppo_xp *h);
  * returns to it (synchronises).  n != num_envs => PPO_XP_EINVAL (buffer.rs:194). */
 int ppo_xp_returns(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out);
 
-/* ppo_xp_returns for callers that cannot allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same arguments, results and bits as
- * ppo_xp_returns; the difference is where the associative scan (PPO_XP_GAE_ASSOC) keeps its chunk maps and
- * carries: ppo_xp_returns grows three device arrays on demand (hipMalloc), this entry point uses a
- * file-scope __device__ array of 3 x 2^20 floats (12 MiB, held by every GPU the library runs on until the
- * process ends) and calls no hipMalloc / hipFree / allocating routine; per-kernel profiling events are
- * taken from the handle's pool only.  Limit: chunks x num_envs <= 2^20 (chunks = ceil(len / chunk
- * length); choose longer chunks with PPO_XP_GAE_CHUNK) - beyond it the call fails with PPO_XP_EINVAL
- * and does nothing.  Every call on one GPU shares that GPU's array: nothing in it has to start at zero
- * (each call writes every entry it later reads), but calls that overlap on one GPU - two handles on two
- * streams - race on it. */
+/* ppo_xp_returns for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that
+ * runs between the allocations of a captured region).  NO COUNTERPART IN THE REFERENCE.  Same arguments, results and
+ * bits as ppo_xp_returns; the difference is where the associative scan (PPO_XP_GAE_ASSOC) keeps its chunk maps and
+ * carries: ppo_xp_returns grows three device arrays on demand (hipMalloc), this entry point uses a file-scope
+ * __device__ array of 3 x 2^20 floats (12 MiB, held by every GPU the library runs on until the process ends) and
+ * calls no hipMalloc / hipFree / allocating routine; per-kernel profiling events are taken from the handle's pool only.
+ * Limit: chunks x num_envs <= 2^20 (chunks = ceil(len / chunk length); choose longer chunks with PPO_XP_GAE_CHUNK) -
+ * beyond it the call fails with PPO_XP_EINVAL BEFORE anything changes (ring state, pass state, last_dones slots).
+ * Every call on one GPU shares that GPU's array: nothing in it has to start at zero (each call writes every entry it
+ * later reads), but calls that overlap on one GPU - two handles on two streams - race on it.
+ * NOT a capturable call: like ppo_xp_returns it consumes `last_dones` AT CALL TIME (host copy into one of eight
+ * page-locked slots the kernels read in place; every fourth call waits on / records an event for slot reuse), so a
+ * HIP graph captured around it would replay with whatever that slot holds later.  Allocation-free, not capture-safe. */
 int ppo_xp_returns_noalloc(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo, float *host_out);
 
 /* explained_variance(values, returns) of train() (ppo/src/training.rs:88-99, called at :189):
@@ -233,6 +235,16 @@ int ppo_xp_pass_next(ppo_xp *h, ppo_batch_view *out);
  * and synchronises.  Same return values as ppo_xp_pass_next; io->capacity < B => PPO_XP_EINVAL and
  * the minibatch is not consumed. */
 int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io);
+/* The same hand-off with the download of minibatch k+1 OVERLAPPING the caller's work on k (the reference's loop is
+ * `for batch in exp_batcher.into_iter() { learner.step(batch) }`, training.rs:205-207: copy_from + step of k take time).
+ * The caller owns TWO slots (page-locked: ppo_xp_host_alloc) and alternates them:
+ *     ppo_xp_pass_next_host_pipelined(h, &A, &B);  consume A;  ..._pipelined(h, &B, &A);  consume B;  ...
+ * The call returns minibatch k in `cur` - already on its way if the previous call named `cur` as its `next_slot`, so
+ * the only wait is one event - and, before returning, enqueues the six copies of minibatch k+1 into `next_slot`
+ * (may be NULL: no prefetch) on a copy stream of the handle.  `next_slot` must not be touched until the call that
+ * passes it as `cur` returns.  Whole-pass mode only (PPO_XP_ESTATE in streaming mode).  Same bits as
+ * ppo_xp_pass_next_host; same return values.  No counterpart in the reference. */
+int ppo_xp_pass_next_host_pipelined(ppo_xp *h, ppo_batch_host *cur, ppo_batch_host *next_slot);
 /* Starts drawing the host Fisher-Yates permutation for `seed` (and the current len) on a worker
  * thread; a later ppo_xp_pass_begin(h, B, NULL, seed) with the same seed and M takes it instead of
  * shuffling on the caller's thread (the reference draws a fresh permutation per pass, training.rs:204-205:
@@ -256,7 +268,8 @@ size_t ppo_xp_pass_num_batches(const ppo_xp *h);
 const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *h);
 int ppo_xp_pass_perm_host(ppo_xp *h, uint32_t *out, size_t n);
 /* Per-minibatch (mean, unbiased std) of the current pass, K pairs of f32 to the host
- * (synchronises).  correct_std: data.rs:196-200. */
+ * (synchronises).  correct_std: data.rs:196-200.  Streaming mode: minibatch k's pair exists only once ppo_xp_pass_next
+ * has gathered it, so the call fails with PPO_XP_ESTATE until the pass is exhausted. */
 int ppo_xp_pass_stats_host(ppo_xp *h, float *mean_std_out, size_t k);
 
 /* ---- env-sharded multi-GPU (no counterpart in the reference, which is single device) --- */
@@ -325,10 +338,13 @@ int ppo_xp_prof_enable(ppo_xp *h, int enable);
 int ppo_xp_prof_collect(ppo_xp *h, double *ms_out /*[K_COUNT]*/, uint64_t *launches_out /*[K_COUNT]*/);
 const char *ppo_xp_kernel_name(int kernel_id);
 
-/* Tunables (A/B measurements in one process; results never depend on them except through the
- * documented tolerance of PPO_XP_GAE_ASSOC): "gather_nt" 0/1, "gather_block" 64/256, "gather_xcd" 0/1/2, "fold_tiles" 0..65536 (single-GPU passes with at most this many 256-row tiles per
+/* Tunables (A/B measurements in one process).  Rows, scalar streams, returns and the sequential scan's results never
+ * depend on them; standardised advantages are bit-identical for a fixed gather route and agree within 1 ulp of the
+ * fp32 mean / std across routes (the fused and the split gathers tile the fp64 sums differently: 32-row against 256-row
+ * tiles - identical bits were observed in every test, they are not guaranteed); PPO_XP_GAE_ASSOC has its documented
+ * tolerance.  Changing a tunable ends a streamed pass in progress (its launch shapes were fixed at pass_begin). "gather_nt" 0/1, "gather_block" 64/256, "gather_xcd" 0/1/2, "fold_tiles" 0..65536 (single-GPU passes with at most this many 256-row tiles per
  * minibatch skip the finalize launch: the standardise workgroups add the tile sums themselves),
- * "gae_waves" 0 (auto)/1/2/4/8/16 (waves per 64 envs of the sequential scan), "gae_unroll" 0 (auto)/4/8/16,
+ * "gae_waves" 0 (auto)/1/2/4/8/16 (waves per 64 envs of the sequential scan), "gae_unroll" 0 (auto)/4/8/16/32,
  * "carry_waves" 4/8/16, "gae_nt", "summary_nt", "rec_nt", "out_nt" 0/1 (cache policy of the streams),
  * "gae_flat" 0/1 (1: the packing scan always stores the flat returns / advantages arrays too),
  * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),

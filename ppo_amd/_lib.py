@@ -80,6 +80,7 @@ SYMBOLS = {
     "ppo_xp_explained_variance_from_sums": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_float)]),
     "ppo_xp_pass_next": (_i, [_vp, C.POINTER(BatchView)]),
     "ppo_xp_pass_next_host": (_i, [_vp, C.POINTER(BatchHost)]),
+    "ppo_xp_pass_next_host_pipelined": (_i, [_vp, C.POINTER(BatchHost), C.POINTER(BatchHost)]),
     "ppo_xp_shuffle_prefetch": (_i, [_vp, _u64]),
     "ppo_xp_pass_gather_kind": (_i, [_vp]),
     "ppo_xp_set_streaming": (_i, [_vp, _i]),

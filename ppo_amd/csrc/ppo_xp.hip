@@ -156,6 +156,11 @@ struct ppo_xp {
   // scalar streams, the statistics (and the exchange) and the standardisation; joined before the pass is handed out
   hipStream_t side = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr; bool side_pending = false;
   unsigned pin_next = 0;
+  // overlapped host hand-off (ppo_xp_pass_next_host_pipelined): minibatch k+1 travels to the caller's second slot on a
+  // copy stream of the handle while the caller consumes k
+  hipStream_t xfer = nullptr; hipEvent_t xfer_fork = nullptr, xfer_done = nullptr; bool xfer_used = false;
+  bool hp_valid = false; size_t hp_k = 0; const void *hp_obs = nullptr; uint64_t hp_pass = 0;   // the prefetch in flight
+  uint64_t pass_serial = 0;
   const uint8_t *last_dones_cur = nullptr;   // device address of the slot of the current call
   float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
   size_t scan_cap = 0;       // elements allocated in carry/sumP/sumQ
@@ -294,6 +299,24 @@ int launch_gae_wide(ppo_xp *h, const GaeArgs &a, unsigned W) {
   return launch_check("gae_wide_kernel");
 }
 
+// Chunk length and count of the associative scan for `len` time steps (bits 16..31 of algo force the length).
+void gae_chunking(const ppo_xp *h, int algo, size_t len, unsigned &L_out, unsigned &chunks_out) {
+  unsigned L = ((unsigned)algo >> 16) & 0xffffu;
+  const unsigned groups = (unsigned)((h->N + 63) / 64);
+  if (L == 0) {
+    // enough (chunk, env-group) waves to fill 256 CUs several times over, chunks >= 32 steps
+    // (C4, 16 env groups: 128 chunks of 128 steps = 114 us, 256 x 64 = 122 us, 64 x 256 = 123 us)
+    unsigned want = std::max(1u, 2048u / groups);
+    unsigned c = (unsigned)std::min<size_t>(want, (len + 31) / 32);
+    c = std::max(c, 1u);
+    L = (unsigned)((len + c - 1) / c);
+  }
+  L = std::max(1u, std::min<unsigned>(L, (unsigned)len));
+  unsigned chunks = (unsigned)((len + L - 1) / L);
+  if (chunks > 65535u) { L = (unsigned)((len + 65534) / 65535); chunks = (unsigned)((len + L - 1) / L); }
+  L_out = L; chunks_out = chunks;
+}
+
 // static_scratch != nullptr: the chunk maps and carries of the associative scan live there (3 x kScratchPairs
 // floats) and nothing is allocated; else in the handle's own buffers, grown on demand.
 int run_gae(ppo_xp *h, int algo, bool want_flat, float *static_scratch = nullptr) {
@@ -311,22 +334,7 @@ int run_gae(ppo_xp *h, int algo, bool want_flat, float *static_scratch = nullptr
   a.gl = h->gamma * h->lambda;  // one fp32 product, computed first (buffer.rs:219)
   unsigned chunks = 1;
   a.chunk = (unsigned)len;
-  if (kind == PPO_XP_GAE_ASSOC) {
-    unsigned L = ((unsigned)algo >> 16) & 0xffffu;
-    const unsigned groups = (unsigned)((N + 63) / 64);
-    if (L == 0) {
-      // enough (chunk, env-group) waves to fill 256 CUs several times over, chunks >= 32 steps
-      // (C4, 16 env groups: 128 chunks of 128 steps = 114 us, 256 x 64 = 122 us, 64 x 256 = 123 us)
-      unsigned want = std::max(1u, 2048u / groups);
-      unsigned c = (unsigned)std::min<size_t>(want, (len + 31) / 32);
-      c = std::max(c, 1u);
-      L = (unsigned)((len + c - 1) / c);
-    }
-    L = std::max(1u, std::min<unsigned>(L, (unsigned)len));
-    chunks = (unsigned)((len + L - 1) / L);
-    if (chunks > 65535u) { L = (unsigned)((len + 65534) / 65535); chunks = (unsigned)((len + L - 1) / L); }
-    a.chunk = L;
-  }
+  if (kind == PPO_XP_GAE_ASSOC) gae_chunking(h, algo, len, a.chunk, chunks);
   if (chunks > 1) {
     const size_t need = (size_t)chunks * N;
     if (static_scratch) {
@@ -486,6 +494,7 @@ int ensure_pass_buffers(ppo_xp *h, size_t K, size_t B, size_t tile_rows) {
   const size_t rows = h->streaming ? 2 * B : std::max(K * B, B <= Mcap ? ((Mcap + B - 1) / B) * B : (size_t)0);
   if (rows > h->slab_rows) {
     HIP_TRY(hipStreamSynchronize(h->stream));   // kernels of the previous pass may still write the old slabs
+    if (h->xfer) HIP_TRY(hipStreamSynchronize(h->xfer));   // ... and host copies may still read them
     dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out);
     dev_free(h->ret_out); dev_free(h->adv_out); h->slab_rows = 0;
     if (int rc = dev_alloc(&h->obs_out, rows * h->D, false)) return rc;
@@ -727,6 +736,8 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   if (!h->have_returns || h->ret_len != len)
     return fail(PPO_XP_ESTATE, "pass_begin: call ppo_xp_returns() first (ExperienceBatcher::new takes the returns, data.rs:27)");
   if (int rc = side_wait(h)) return rc;                      // rows of an abandoned pass (begun, never finished) on the side stream
+  if (h->xfer_used) HIP_TRY(hipStreamWaitEvent(h->stream, h->xfer_done, 0));   // host copies of the previous pass still read the slabs
+  h->hp_valid = false; ++h->pass_serial;
   h->pass_B = B; h->pass_M = M; h->pass_iter = 0; h->pass_active = true; h->pass_pending_finish = false;
   h->pass_K = (B > M) ? 0 : (M + B - 1) / B;                 // data.rs:117-126
   h->pass_streamed = h->streaming;
@@ -858,6 +869,10 @@ void ppo_xp_destroy(ppo_xp *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->side) (void)hipStreamSynchronize(h->side);
+  if (h->xfer) (void)hipStreamSynchronize(h->xfer);
+  if (h->xfer_fork) (void)hipEventDestroy(h->xfer_fork);
+  if (h->xfer_done) (void)hipEventDestroy(h->xfer_done);
+  if (h->xfer) (void)hipStreamDestroy(h->xfer);
   for (auto &r : h->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto e : h->pin_ev) if (e) (void)hipEventDestroy(e);
@@ -1053,6 +1068,13 @@ static int returns_impl(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo
   const int kind = algo & 0xff;
   if (kind != PPO_XP_GAE_SEQUENTIAL && kind != PPO_XP_GAE_ASSOC) return fail(PPO_XP_EINVAL, "returns: unknown algo %d", algo);
   HIP_TRY(hipSetDevice(h->device));
+  if (static_scratch && kind == PPO_XP_GAE_ASSOC && buf_len(h)) {   // refuse BEFORE anything changes: the call then does nothing
+    unsigned L = 0, chunks = 1;
+    gae_chunking(h, algo, buf_len(h), L, chunks);
+    if (chunks > 1 && (size_t)chunks * h->N > kScratchPairs)
+      return fail(PPO_XP_EINVAL, "returns_noalloc: %u chunks x %zu envs = %zu chunk maps, the static scratch holds %zu "
+                  "(use fewer, longer chunks with PPO_XP_GAE_CHUNK, or ppo_xp_returns)", chunks, h->N, (size_t)chunks * h->N, kScratchPairs);
+  }
   // slot ring (see the handle): calls 4b .. 4b+3 form block b; the event of block b is recorded after its last
   // scan and waited for when block b+2 (which reuses its slots) starts
   const unsigned call = h->pin_next++;
@@ -1278,6 +1300,66 @@ int ppo_xp_pass_next_host(ppo_xp *h, ppo_batch_host *io) {
   return 0;
 }
 
+// Six device-to-host copies of minibatch k (rows [row, row + B) of the slabs) into `io`, on the copy stream, ordered
+// after everything the handle's stream holds now; xfer_done is recorded behind them.
+static int enqueue_host_copies(ppo_xp *h, size_t row, const ppo_batch_host *io) {
+  if (!h->xfer) {
+    HIP_TRY(hipStreamCreateWithFlags(&h->xfer, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&h->xfer_fork, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->xfer_done, hipEventDisableTiming));
+  }
+  const size_t B = h->pass_B, D = h->D;
+  HIP_TRY(hipEventRecord(h->xfer_fork, h->stream));
+  HIP_TRY(hipStreamWaitEvent(h->xfer, h->xfer_fork, 0));
+  HIP_TRY(hipMemcpyAsync(io->observations, h->obs_out + row * D, B * D * sizeof(float), hipMemcpyDeviceToHost, h->xfer));
+  HIP_TRY(hipMemcpyAsync(io->actions, h->act_out + row, B * sizeof(int64_t), hipMemcpyDeviceToHost, h->xfer));
+  HIP_TRY(hipMemcpyAsync(io->values, h->val_out + row, B * sizeof(float), hipMemcpyDeviceToHost, h->xfer));
+  HIP_TRY(hipMemcpyAsync(io->neglogps, h->nlp_out + row, B * sizeof(float), hipMemcpyDeviceToHost, h->xfer));
+  HIP_TRY(hipMemcpyAsync(io->returns, h->ret_out + row, B * sizeof(float), hipMemcpyDeviceToHost, h->xfer));
+  HIP_TRY(hipMemcpyAsync(io->advantages, h->adv_out + row, B * sizeof(float), hipMemcpyDeviceToHost, h->xfer));
+  HIP_TRY(hipEventRecord(h->xfer_done, h->xfer));
+  h->xfer_used = true;
+  return 0;
+}
+
+static bool host_slot_ok(const ppo_batch_host *io) {
+  return io->observations && io->actions && io->values && io->neglogps && io->returns && io->advantages;
+}
+
+int ppo_xp_pass_next_host_pipelined(ppo_xp *h, ppo_batch_host *cur, ppo_batch_host *next_slot) {
+  if (!h || !cur) return fail(PPO_XP_EINVAL, "pass_next_host_pipelined: NULL argument");
+  if (!host_slot_ok(cur) || (next_slot && !host_slot_ok(next_slot)))
+    return fail(PPO_XP_EINVAL, "pass_next_host_pipelined: the six destination arrays of a slot must be set by the caller");
+  if (next_slot && next_slot->observations == cur->observations)
+    return fail(PPO_XP_EINVAL, "pass_next_host_pipelined: the two slots must be different arrays");
+  if (!h->pass_active) return fail(PPO_XP_ESTATE, "pass_next: no pass (call ppo_xp_pass_begin)");
+  if (h->pass_pending_finish) return fail(PPO_XP_ESTATE, "pass_next: statistics exchange pending (call ppo_xp_pass_finish)");
+  if (h->pass_streamed)
+    return fail(PPO_XP_ESTATE, "pass_next_host_pipelined: needs the whole-pass slabs (not with ppo_xp_set_streaming); use ppo_xp_pass_next_host");
+  const size_t B = h->pass_B, M = h->pass_M, K = h->pass_K;
+  if (B > M || h->pass_iter >= M) { h->hp_valid = false; return 1; }          // data.rs:117-119 -> None
+  if (cur->capacity < B || (next_slot && next_slot->capacity < B))
+    return fail(PPO_XP_EINVAL, "pass_next_host_pipelined: a slot holds fewer rows than the minibatch (%zu)", B);
+  HIP_TRY(hipSetDevice(h->device));
+  const size_t k = h->pass_iter / B;
+  const bool hit = h->hp_valid && h->hp_pass == h->pass_serial && h->hp_k == k && h->hp_obs == cur->observations;
+  if (!hit) {
+    // nothing (or something else) was prefetched: first minibatch of a pass, or the caller changed slots
+    if (h->hp_valid) HIP_TRY(hipEventSynchronize(h->xfer_done));   // a stale prefetch must not land in a slot the caller reuses
+    if (int rc = enqueue_host_copies(h, k * B, cur)) return rc;
+  }
+  h->hp_valid = false;
+  HIP_TRY(hipEventSynchronize(h->xfer_done));                       // minibatch k has arrived (the only wait of the call)
+  h->pass_iter += B;                                                // data.rs:126
+  cur->index = k; cur->batch_size = B; cur->obs_size = h->D;
+  if (next_slot && k + 1 < K) {
+    // minibatch k+1 starts travelling now, while the caller consumes k (copy_from + learner.step, training.rs:205-207)
+    if (int rc = enqueue_host_copies(h, (k + 1) * B, next_slot)) return rc;
+    h->hp_valid = true; h->hp_k = k + 1; h->hp_obs = next_slot->observations; h->hp_pass = h->pass_serial;
+  }
+  return 0;
+}
+
 int ppo_xp_pass_gather_kind(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_kind : -1; }
 size_t ppo_xp_pass_num_batches(const ppo_xp *h) { return (h && h->pass_active) ? h->pass_K : 0; }
 const uint32_t *ppo_xp_pass_perm_device(const ppo_xp *hc) {
@@ -1305,6 +1387,9 @@ int ppo_xp_pass_stats_host(ppo_xp *h, float *mean_std_out, size_t k) {
   if (!h || !mean_std_out) return fail(PPO_XP_EINVAL, "pass_stats_host: NULL argument");
   if (!h->pass_active || h->pass_pending_finish) return fail(PPO_XP_ESTATE, "pass_stats_host: no finished pass");
   if (k != h->pass_K) return fail(PPO_XP_EINVAL, "pass_stats_host: k = %zu, pass has %zu minibatches", k, h->pass_K);
+  if (h->pass_streamed && h->pass_K && h->pass_iter < h->pass_K * h->pass_B)
+    return fail(PPO_XP_ESTATE, "pass_stats_host: a streamed pass knows minibatch k's statistics only after ppo_xp_pass_next has gathered it; "
+                "%zu of %zu minibatches so far", h->pass_iter / h->pass_B, h->pass_K);
   HIP_TRY(hipSetDevice(h->device));
   if (k) HIP_TRY(hipMemcpyAsync(mean_std_out, h->stats, 2 * k * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1318,6 +1403,7 @@ int ppo_xp_set_streaming(ppo_xp *h, int on) {
     // the slabs change size: drop them (after the stream has finished with them); the next pass re-allocates
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->xfer) HIP_TRY(hipStreamSynchronize(h->xfer));
     dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out); dev_free(h->adv_out);
     h->slab_rows = 0;
     h->pass_active = false;
@@ -1392,6 +1478,7 @@ int ppo_xp_set_stream(ppo_xp *h, void *stream) {
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->side_pending) HIP_TRY(hipStreamSynchronize(h->side));   // its join event stays valid for the new stream
+  if (h->xfer) HIP_TRY(hipStreamSynchronize(h->xfer));
   if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
   h->stream = (hipStream_t)stream;
   return 0;
@@ -1429,6 +1516,9 @@ int ppo_xp_prof_collect(ppo_xp *h, double *ms_out, uint64_t *launches_out) {
 int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   if (!h || !name) return fail(PPO_XP_EINVAL, "set_tunable: NULL argument");
   std::string n(name);
+  // a streamed pass launches per minibatch with shapes fixed at pass_begin (partials, tiles): a tunable changed in the
+  // middle would mix them, so it ends the pass
+  if (h->pass_active && h->pass_streamed) h->pass_active = false;
   if (n == "gather_nt" && (value == 0 || value == 1)) h->gather_nt = value;
   else if (n == "gather_block" && (value == 64 || value == 256)) h->gather_block = value;
   else if (n == "fold_tiles" && value >= 0 && value <= 65536) h->fold_tiles = value;

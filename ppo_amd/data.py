@@ -166,13 +166,22 @@ class ExperienceBatcherIterator:
         return self
 
     def __next__(self) -> ExperienceBatch:
+        """Streaming mode (buffer.set_streaming): the tensors are zero-copy views of slot k % 2 and are OVERWRITTEN by the
+        call after the next one - consume or clone a minibatch before asking for the one after next; `list(iterator)`
+        would keep K aliases of two slots."""
         import torch
         buf = self.batcher.buffer
         v = _lib.BatchView()
         rc = check(self.batcher._L.ppo_xp_pass_next(buf.handle, C.byref(v)))
         if rc == 1:
             raise StopIteration
-        if v.index == 0 or buf.streaming:      # streaming: this very call enqueued the minibatch's kernels
+        if buf.streaming:
+            # this very call enqueued minibatch k's kernels on the handle's stream: order torch's current stream behind
+            # them (no host wait, so the consumer's work on k overlaps the gather of k+1)
+            cur, hs = buf._order_streams()
+            if hs is not None:
+                cur.wait_stream(hs)
+        elif v.index == 0:
             buf.sync()
         B, D, d = v.batch_size, v.obs_size, buf.device
         f32, i64 = torch.float32, torch.int64
@@ -184,14 +193,35 @@ class ExperienceBatcherIterator:
     def next_host(self, out: "HostBatch | None" = None) -> "HostBatch | None":
         """Iterator::next as the reference's caller sees it (data.rs:166-182 feeds six host Vecs to
         copy_from): minibatch k copied into host arrays (page-locked when `out` comes from
-        HostBatch.pinned).  Returns None when the pass is exhausted."""
+        HostBatch.pinned).  Returns None when the pass is exhausted.  With out=None every call fills the SAME page-locked
+        set owned by the iterator: copy what must outlive the next call."""
         buf = self.batcher.buffer
-        if out is None:
-            out = HostBatch.pinned(self.batcher.batch_size, buf.obs_size)
+        if out is None:      # one page-locked set per iterator, reused by every call (a fresh hipHostMalloc per minibatch costs more than the copy)
+            if getattr(self, "_host_batch", None) is None:
+                self._host_batch = HostBatch.pinned(self.batcher.batch_size, buf.obs_size)
+            out = self._host_batch
         rc = check(self.batcher._L.ppo_xp_pass_next_host(buf.handle, C.byref(out._c)))
         if rc == 1:
             return None
         return out.view(out._c.batch_size, out._c.index)
+
+    def host_batches(self, slots=None):
+        """Generator over the pass as HOST minibatches with the download of k+1 overlapping the consumer's work on k
+        (ppo_xp_pass_next_host_pipelined): two page-locked slots alternate, so a yielded batch is valid until the one
+        after next is asked for.  `slots`: two HostBatch objects (default: a page-locked pair owned by the iterator)."""
+        buf = self.batcher.buffer
+        if slots is None:
+            if getattr(self, "_host_pair", None) is None:
+                self._host_pair = (HostBatch.pinned(self.batcher.batch_size, buf.obs_size),
+                                   HostBatch.pinned(self.batcher.batch_size, buf.obs_size))
+            slots = self._host_pair
+        a, b = slots
+        while True:
+            rc = check(self.batcher._L.ppo_xp_pass_next_host_pipelined(buf.handle, C.byref(a._c), C.byref(b._c)))
+            if rc == 1:
+                return
+            yield a.view(a._c.batch_size, a._c.index)
+            a, b = b, a
 
     def perm(self) -> np.ndarray:
         """The permutation of this pass (host copy)."""

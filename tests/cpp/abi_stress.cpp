@@ -245,6 +245,49 @@ int main() {
     REQUIRE(ppo_xp_pass_next_host(h, &io) == PPO_XP_EINVAL);                  // destination too small: not consumed
     io.capacity = 224;
     REQUIRE(ppo_xp_pass_next_host(h, &io) == 0 && io.index == 0);
+    // overlapped hand-off: two page-locked slots alternate; minibatch k+1 travels while k is "consumed".  Every host
+    // batch must hold the bits of the synchronous hand-off above (adv_whole) and the rows of storage[perm]
+    {
+      ppo_batch_host sl[2]{};
+      for (auto &q : sl) {
+        q.capacity = 224;
+        q.observations = (float *)ppo_xp_host_alloc(224 * D * sizeof(float)); q.actions = (size_t *)ppo_xp_host_alloc(224 * sizeof(size_t));
+        q.values = (float *)ppo_xp_host_alloc(224 * 4); q.neglogps = (float *)ppo_xp_host_alloc(224 * 4);
+        q.returns = (float *)ppo_xp_host_alloc(224 * 4); q.advantages = (float *)ppo_xp_host_alloc(224 * 4);
+        REQUIRE(q.observations && q.actions && q.values && q.neglogps && q.returns && q.advantages);
+      }
+      REQUIRE(ppo_xp_pass_begin(h, 224, nullptr, 77) == 0);
+      REQUIRE(ppo_xp_pass_next_host_pipelined(h, &sl[0], &sl[0]) == PPO_XP_EINVAL);       // one slot twice
+      size_t k = 0;
+      while (true) {
+        ppo_batch_host *cur = &sl[k & 1], *nxt = &sl[(k + 1) & 1];
+        const int rc = ppo_xp_pass_next_host_pipelined(h, cur, k == 3 ? nullptr : nxt);   // one call without a prefetch: the next one copies on demand
+        REQUIRE(rc == 0 || rc == 1);
+        if (rc == 1) break;
+        REQUIRE(cur->index == k && cur->batch_size == 224 && cur->obs_size == D);
+        REQUIRE(std::memcmp(cur->advantages, &adv_whole[k * 224], 224 * sizeof(float)) == 0);
+        const size_t start = std::min(k * 224, M - 224);
+        for (size_t j = 0; j < 224; ++j) {
+          const uint32_t src = p1[start + j];
+          REQUIRE(std::memcmp(&cur->observations[j * D], &store_obs[src * D], D * sizeof(float)) == 0);
+          REQUIRE((int64_t)cur->actions[j] == store_act[src] && cur->values[j] == store_val[src]);
+        }
+        std::memset(cur->observations, 0xff, 224 * D * sizeof(float));                    // "consumed": a late copy into it would show
+        ++k;
+      }
+      REQUIRE(k == nb);
+      // a new pass while a prefetch could still be in flight, then the synchronous hand-off: ordered, same bits
+      REQUIRE(ppo_xp_pass_begin(h, 224, nullptr, 77) == 0);
+      REQUIRE(ppo_xp_pass_next_host_pipelined(h, &sl[0], &sl[1]) == 0);
+      REQUIRE(ppo_xp_pass_begin(h, 224, nullptr, 77) == 0);
+      REQUIRE(ppo_xp_pass_next_host(h, &io) == 0 && io.index == 0);
+      REQUIRE(std::memcmp(ha.data(), &adv_whole[0], 224 * sizeof(float)) == 0);
+      REQUIRE(ppo_xp_sync(h) == 0);
+      for (auto &q : sl) {
+        ppo_xp_host_free(q.observations); ppo_xp_host_free(q.actions); ppo_xp_host_free(q.values);
+        ppo_xp_host_free(q.neglogps); ppo_xp_host_free(q.returns); ppo_xp_host_free(q.advantages);
+      }
+    }
     // streaming: two slots, same bits
     REQUIRE(ppo_xp_set_streaming(h, 1) == 0);
     REQUIRE(ppo_xp_set_exchange(h, 2, nullptr) == PPO_XP_ESTATE);

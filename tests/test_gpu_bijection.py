@@ -122,3 +122,44 @@ def test_tgt_size_bijection_and_rows(xp):
         assert (ad.double() - ref).abs().max().item() < 2e-6
     buf.close()
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("T,N,D,B,bijection", [(16, 256, 64, 512, True), (9, 130, 16, 320, False), (5, 64, 8, 320, False)])
+def test_pipelined_host_handoff_matches_the_oracle(xp, oracle, T, N, D, B, bijection):
+    """ppo_xp_pass_next_host_pipelined (data.rs:166-182 as the caller sees it, with the download of minibatch k+1
+    overlapping the consumer's work on k): every host batch against the oracle, bit for bit, under the overlapped
+    schedule - the consumer scribbles over a slot after use, so a copy that lands late or in the wrong slot shows."""
+    g, o, r = both(xp, oracle, T, N, D, T, seed=11)
+    ret_o = o.returns(r["last_dones"])
+    g.returns(r["last_dones"])
+    obs_o, act_o, val_o, nlp_o = o.training_views()
+    adv_o = oracle.advantages(ret_o, val_o)
+    M = T * N
+    batcher = xp.ExperienceBatcher(g, B)
+    for rep in range(2):
+        it = batcher.into_iter(seed=40 + rep, bijection=bijection)
+        perm = it.perm()
+        np.testing.assert_array_equal(perm, oracle.bijection_perm(40 + rep, M) if bijection else oracle.shuffle(40 + rep, M))
+        windows = oracle.batch_windows(M, B)
+        n = 0
+        for k, b in enumerate(it.host_batches()):
+            s, e = windows[k]
+            idx = perm[s:e]
+            assert b.index == k
+            np.testing.assert_array_equal(bits(b.observations), bits(oracle.gather_f32(obs_o, idx)))
+            np.testing.assert_array_equal(b.actions, oracle.gather_u64(act_o, idx))
+            np.testing.assert_array_equal(bits(b.values), bits(oracle.gather_f32(val_o, idx)))
+            np.testing.assert_array_equal(bits(b.neglogps), bits(oracle.gather_f32(nlp_o, idx)))
+            np.testing.assert_array_equal(bits(b.returns), bits(oracle.gather_f32(ret_o, idx)))
+            want64, _, s64 = oracle.standardize_f64(oracle.gather_f32(adv_o, idx))
+            if s64 > 1e-3:
+                np.testing.assert_allclose(b.advantages, want64, rtol=0, atol=2e-6 * max(1.0, np.abs(want64).max()) + 1e-6)
+            for a in (b.observations, b.values, b.neglogps, b.returns, b.advantages):
+                a.fill(np.nan)
+            n += 1
+        assert n == len(windows)
+    g.set_streaming(True)
+    it = batcher.into_iter(seed=1)
+    with pytest.raises(xp.PpoXpError):
+        next(it.host_batches())
+    g.close()

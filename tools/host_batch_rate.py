@@ -34,6 +34,38 @@ for kind, mk in (("pinned", ppo_amd.HostBatch.pinned), ("pageable", ppo_amd.Host
         best = min(best, time.perf_counter() - t0)
     print(f"{kind:9s} {n} x pass_next_host of {B} rows: {best * 1e3:7.1f} ms per pass = {nbytes / best / 1e9:5.1f} GB/s "
           f"= {M / best / 1e6:6.1f} M transitions/s", flush=True)
+# a consumer that spends `work` ms on every minibatch (copy_from + learner.step, training.rs:205-207): the synchronous
+# hand-off costs PCIe + consumer, the pipelined one max(PCIe, consumer)
+def consume(ms):
+    t_end = time.perf_counter() + ms * 1e-3
+    while time.perf_counter() < t_end:
+        pass
+
+K = M // B
+for work in (0.0, 1.0, 2.0, 4.0):
+    res = {}
+    for mode in ("synchronous", "pipelined"):
+        best = 1e9
+        for rep in range(3):
+            it = batcher.into_iter(seed=rep, bijection=True)
+            buf.sync()
+            t0 = time.perf_counter()
+            n = 0
+            if mode == "synchronous":
+                hb = it._host_batch = getattr(batcher, "_hb", None) or ppo_amd.HostBatch.pinned(B, D)
+                batcher._hb = hb
+                while it.next_host(hb) is not None:
+                    consume(work); n += 1
+            else:
+                it._host_pair = getattr(batcher, "_pair", None) or (ppo_amd.HostBatch.pinned(B, D), ppo_amd.HostBatch.pinned(B, D))
+                batcher._pair = it._host_pair
+                for b in it.host_batches():
+                    consume(work); n += 1
+            best = min(best, time.perf_counter() - t0)
+        assert n == K
+        res[mode] = best * 1e3
+    print(f"consumer {work:3.1f} ms/minibatch ({K * work:6.1f} ms per pass): synchronous {res['synchronous']:6.1f} ms per pass, "
+          f"pipelined {res['pipelined']:6.1f} ms per pass", flush=True)
 # host Fisher-Yates on the caller's thread vs prefetched by the library's worker while the previous pass is consumed
 t0 = time.perf_counter(); it = batcher.into_iter(seed=100); t_fy = time.perf_counter() - t0
 batcher.prefetch_shuffle(101)
