@@ -42,10 +42,13 @@ extern "C" {
 /* GAE algorithm selector for ppo_xp_returns(). */
 #define PPO_XP_GAE_SEQUENTIAL 0 /* K1: one lane per env, strict reverse-time order; bit-exact
                                    with the reference's fp32 op order (buffer.rs:206-222)   */
-#define PPO_XP_GAE_ASSOC 1      /* K2: time-chunked associative linear-recurrence scan with an
-                                   LDS scan over chunk carries; for long horizons / few envs;
-                                   NOT bit-exact (bound stated in DESIGN.md)                 */
-/* bits 16..31 of `algo`, when non-zero, force the chunk length of PPO_XP_GAE_ASSOC. */
+#define PPO_XP_GAE_ASSOC 1      /* K2: time-chunked associative linear-recurrence scan; for long
+                                   horizons / few envs; NOT bit-exact (bound stated in DESIGN.md).
+                                   Up to 32 768 steps it runs as ONE launch (chunks kept in registers,
+                                   chunk maps exchanged inside the running grid); longer buffers, or a
+                                   forced chunk length, take three launches (chunk maps, LDS carry
+                                   scan, replay).  Deterministic either way.                        */
+/* bits 16..31 of `algo`, when non-zero, force the chunk length of PPO_XP_GAE_ASSOC (three-launch form). */
 #define PPO_XP_GAE_CHUNK(len) ((int)((unsigned)(len) << 16))
 /* do not build the packed per-transition records the gather reads (GAE-only measurements;
  * ppo_xp_pass_begin() then builds them itself on first use). */
@@ -350,7 +353,8 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),
  * "fused_block" 256/512 (its workgroup size), "bij_mode" 0/1/2 (keyed-bijection passes: 0 = always write the index
  * array out first, 1 = one evaluation per output row handed to the row's threads through LDS, 2 = every thread evaluates
- * its own),
+ * its own), "gae_onepass" -1 (by length) / 0 / 1 (PPO_XP_GAE_ASSOC as one launch), "op_l" 16/32/64 and "op_w" 2/4/8/16 (its
+ * chunk length and chunks per workgroup; only some pairs are built),
  * "overlap" 0/1 (1: with the two-kernel path, the observation rows are gathered on a side stream of the handle while
  * the scalar streams, statistics and standardisation run on its own; joined before the pass is handed out).
  * Unknown names or values => PPO_XP_EINVAL. */

@@ -334,6 +334,185 @@ __global__ __launch_bounds__(64 * W) void gae_carry_scan_kernel(const float *__r
   }
 }
 
+// K2 in ONE launch ("one-pass" associative scan).  Same decomposition as the three kernels above - chunk maps (P, Q),
+// carries by map application, exact replay of the recurrence from the carry - but every chunk is loaded from HBM ONCE
+// and kept in registers between the two phases, and the carries are exchanged inside the running grid:
+//   workgroup = W waves = W consecutive chunks of L time steps of one group of 64 envs (a "super-chunk"); work is handed
+//   out by a ticket counter in reverse-time order, so a workgroup only ever waits for workgroups that already run.
+//   phase A  wave w loads its L steps (r, v: L x 2 registers per lane; the done flags of the L rows as two words per lane,
+//            broadcast with readlane), computes delta_t exactly as gae_step does, keeps delta_t, v_t and the
+//            non-terminal bits, and runs the recurrence from A = 0 to get its map  A_out = Q + P * A_in.
+//   publish  the W maps are composed in a fixed order (LDS) into the super-chunk's map, which wave 0 publishes as two
+//            64-bit words {serial tag, float} per env with relaxed agent-scope atomic stores: the tag travels in the
+//            same word as the value, so no fence is needed and nothing has to be cleared between calls.
+//   look-back wave 0 reads the maps of ALL earlier super-chunks (they depend on nothing, so they are published as soon as
+//            their phase A ends: no chain of waits) and applies them one after the other to 0: the carry entering this
+//            super-chunk.  Applying maps in a fixed order makes the result independent of timing: deterministic.
+//   phase B  the carry is pushed through the W maps (LDS), every wave replays its L steps from its carry with the
+//            sequential kernel's three dependent operations per step and stores ret / adv' (or the record halves).
+// HBM traffic: 9 B read + 8 B written per transition, one launch (the three-kernel path reads the inputs twice).
+// The spin on a tag is bounded: a wave that gives up sets *err and finishes, so the grid always drains.
+struct OnePassArgs {
+  GaeArgs a;
+  unsigned long long *words;     // [S][N][2] tagged (P, Q) of every super-chunk
+  unsigned long long *ticket;    // work counter; the workgroup that draws the last ticket resets it to 0
+  unsigned *err;                 // set to 1 when a look-back gave up
+  unsigned serial, S, groups;    // tag of this call (never 0); super-chunks per env group; env groups
+};
+
+constexpr unsigned kOnePassMaxSupers = 64;   // super-chunks per env group the kernel can look back over (LDS: 2 x 16 KB)
+
+__device__ __forceinline__ unsigned long long op_pack(unsigned tag, float x) {
+  return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(x);
+}
+
+template <bool PACK, int L, int W>
+__global__ __launch_bounds__(64 * W) void gae_onepass_kernel(OnePassArgs o) {
+  static_assert(L <= 64, "the non-terminal bits of a chunk live in one 64-bit mask");
+  __shared__ unsigned s_ticket;
+  __shared__ float sP[W][64], sQ[W][64], sY[W][64];
+  __shared__ float lbP[kOnePassMaxSupers][64], lbQ[kOnePassMaxSupers][64];   // maps of the earlier super-chunks
+  const GaeArgs &a = o.a;
+  if (threadIdx.x == 0) {
+    const unsigned long long t = atomicAdd(o.ticket, 1ull);
+    if (t + 1 == (unsigned long long)o.S * o.groups) __hip_atomic_store(o.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ticket = (unsigned)t;
+  }
+  __syncthreads();
+  const unsigned s = s_ticket / o.groups, g = s_ticket - s * o.groups;   // reverse-time order: s = 0 holds the last steps
+  const unsigned lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const unsigned e_raw = g * 64u + lane;
+  const bool live = e_raw < a.N;
+  const size_t N = a.N;
+  const size_t e = live ? e_raw : N - 1;
+  const int len = (int)a.len;
+  const int t_top = len - 1 - (int)((s * W + w) * L);          // latest step of this wave's chunk; < 0: no chunk
+  const int steps = t_top < 0 ? 0 : (t_top + 1 < L ? t_top + 1 : L);
+
+  // ---- phase A: the chunk into registers
+  float dl[L], vv[L];
+  float v_next, nnt_next;
+  unsigned long long mask = 0;                                 // bit u: non-terminal factor used by step u (row t_top - u)
+  if (steps > 0) {                                             // wave-uniform
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+      const size_t i = (size_t)(t_top - u > 0 ? t_top - u : 0) * N + e;
+      if (a.nt) {                                              // every input byte is read exactly once
+        dl[u] = __builtin_nontemporal_load(a.rewards + i);
+        vv[u] = __builtin_nontemporal_load(a.values + i);
+      } else {
+        dl[u] = a.rewards[i];
+        vv[u] = a.values[i];
+      }
+    }
+    // done flags of row t_top - lane, both words of this env group, in lane `lane`
+    const size_t drow = (size_t)(t_top - (int)lane > 0 ? t_top - (int)lane : 0) * a.W + (size_t)((g * 64u) >> 5);
+    const uint32_t dw0 = a.done_bits[drow];
+    const uint32_t dw1 = ((g * 64u) >> 5) + 1 < a.W ? a.done_bits[drow + 1] : 0u;
+    if (t_top == len - 1) {                                    // buffer.rs:209-210, 201-204
+      v_next = a.values[(size_t)a.lvi * N + e];
+      nnt_next = a.last_dones[e] ? 0.0f : 1.0f;
+    } else {                                                   // buffer.rs:212-213, 199
+      v_next = a.values[(size_t)(t_top + 1) * N + e];
+      nnt_next = nnt_of(done_word(a, (size_t)(t_top + 1), (unsigned)e), (unsigned)e);
+    }
+    float A = 0.0f, P = 1.0f;
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+      if (u < steps) {
+        const float x1 = v_next * nnt_next;
+        const float x2 = x1 * a.gamma;
+        const float x3 = dl[u] + x2;
+        const float delta = x3 - vv[u];                        // (rewards + nextvalues*nextnonterminal*gamma) - values
+        dl[u] = delta;
+        if (nnt_next != 0.0f) mask |= 1ull << u;
+        P = P * (nnt_next * a.gl);
+        const float y1 = nnt_next * A;
+        const float y2 = y1 * a.gl;
+        A = delta + y2;
+        v_next = vv[u];
+        const uint32_t word = lane < 32 ? (uint32_t)__builtin_amdgcn_readlane((int)dw0, u) : (uint32_t)__builtin_amdgcn_readlane((int)dw1, u);
+        nnt_next = ((word >> (lane & 31u)) & 1u) ? 0.0f : 1.0f;
+      }
+    }
+    sP[w][lane] = P; sQ[w][lane] = A;
+  } else {
+    sP[w][lane] = 1.0f; sQ[w][lane] = 0.0f;                    // beyond t = 0: the identity map, feeds nobody
+  }
+  __syncthreads();
+
+  // ---- carries: wave 0 publishes the super-chunk's map; ALL waves fetch the maps of the earlier super-chunks (entry i by
+  // wave i mod W: one round trip for the whole list instead of one per batch); wave 0 applies them in order
+  if (w == 0) {
+    float Pa = sP[0][lane], Qa = sQ[0][lane];
+#pragma unroll
+    for (int k = 1; k < W; ++k) {                              // f_k after f_{k-1} ... after f_0, fixed order
+      const float p = sP[k][lane], q = sQ[k][lane];
+      Qa = q + p * Qa;
+      Pa = p * Pa;
+    }
+    unsigned long long *mine = o.words + ((size_t)s * N + e) * 2;
+    if (live) {
+      __hip_atomic_store(mine, op_pack(o.serial, Pa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mine + 1, op_pack(o.serial, Qa), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  {
+    bool gave_up = false;
+    for (unsigned i = w; i < s; i += W) {
+      const unsigned long long *src = o.words + ((size_t)i * N + e) * 2;
+      unsigned long long wp, wq;
+      unsigned spins = 0;
+      for (;;) {
+        wp = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        wq = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool ready = (unsigned)(wp >> 32) == o.serial && (unsigned)(wq >> 32) == o.serial;
+        if (__all(ready)) break;                               // lanes past N read env N - 1's words: published too
+        if (++spins > (1u << 20)) { gave_up = true; break; }   // seconds: something is badly wrong; drain the grid
+        __builtin_amdgcn_s_sleep(8);
+      }
+      if (gave_up) break;
+      lbP[i][lane] = __uint_as_float((unsigned)wp);
+      lbQ[i][lane] = __uint_as_float((unsigned)wq);
+    }
+    if (gave_up && lane == 0) atomicExch(o.err, 1u);
+  }
+  __syncthreads();
+  if (w == 0) {
+    float Y = 0.0f;                                            // buffer.rs:196 for the super-chunk that holds the last steps
+    for (unsigned i = 0; i < s; ++i) Y = lbQ[i][lane] + lbP[i][lane] * Y;
+    sY[0][lane] = Y;
+#pragma unroll
+    for (int k = 0; k + 1 < W; ++k) {
+      Y = sQ[k][lane] + sP[k][lane] * Y;
+      sY[k + 1][lane] = Y;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: exact replay from the carry (the sequential kernel's operations, in its order)
+  if (steps > 0 && live) {
+    float A = sY[w][lane];
+#pragma unroll
+    for (int u = 0; u < L; ++u) {
+      if (u < steps) {
+        const float nnt = ((mask >> u) & 1ull) ? 1.0f : 0.0f;
+        const float y1 = nnt * A;
+        const float y2 = y1 * a.gl;
+        A = dl[u] + y2;                                        // lastgaelam = delta + nextnonterminal*lastgaelam*(gamma*lambda)
+        const float ret = A + vv[u];                           // buffer.rs:222
+        const float adv = ret - vv[u];                         // data.rs:62
+        const size_t i = (size_t)(t_top - u) * N + e;
+        if (!PACK || a.flat) {
+          if (a.nt) { __builtin_nontemporal_store(ret, a.returns + i); __builtin_nontemporal_store(adv, a.adv + i); }
+          else { a.returns[i] = ret; a.adv[i] = adv; }
+        }
+        if (PACK) store_rec_scan(a.rec, i, vv[u], ret);
+      }
+    }
+  }
+}
+
 // Scan halves from the flat streams (only needed after a PPO_XP_GAE_NO_PACK returns()).
 __global__ __launch_bounds__(256) void pack_records_kernel(const float *__restrict__ values,
                                                            const float *__restrict__ returns,

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -100,7 +101,9 @@ constexpr int kNcclFloat64 = 8, kNcclSum = 0;  // rccl.h: ncclFloat64 = 8, ncclS
 // every kernel argument below is that pointer, never the name.
 // ---------------------------------------------------------------------------------------
 constexpr size_t kScratchPairs = size_t(1) << 20;           // (chunk, env) pairs one call may use
-static __device__ __align__(256) float scratch[3 * kScratchPairs];   // [0]: P  [1]: Q  [2]: carry
+constexpr size_t kScratchOnePassWords = size_t(1) << 19;    // tagged 64-bit words of the one-pass scan: (super-chunk, env) pairs x 2
+// [0]: P  [1]: Q  [2]: carry  (three-kernel scan, floats) | one-pass scan: tagged words, then its ticket counter and error flag
+static __device__ __align__(256) float scratch[3 * kScratchPairs + 2 * kScratchOnePassWords + 64];
 namespace {
 constexpr int kMaxDevices = 64;
 float *g_scratch_ptr[kMaxDevices] = {};
@@ -164,6 +167,8 @@ struct ppo_xp {
   const uint8_t *last_dones_cur = nullptr;   // device address of the slot of the current call
   float *carry = nullptr, *sumP = nullptr, *sumQ = nullptr;
   size_t scan_cap = 0;       // elements allocated in carry/sumP/sumQ
+  unsigned long long *op_words = nullptr; size_t op_cap = 0;   // one-pass scan: tagged maps [S][N][2] + ticket + error flag behind them
+  unsigned *op_err_pending = nullptr;                           // error flag of a one-pass launch nobody has looked at yet
   bool have_returns = false, have_rec = false;
   bool have_flat = false;    // the flat returns / adv arrays hold the current GAE results (else only the records do)
   size_t ret_len = 0;        // len at the time of returns()
@@ -200,7 +205,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0, bij_mode = 1;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0, bij_mode = 1, gae_onepass = -1, op_l = 32, op_w = 16;
 };
 
 namespace {
@@ -299,6 +304,82 @@ int launch_gae_wide(ppo_xp *h, const GaeArgs &a, unsigned W) {
   return launch_check("gae_wide_kernel");
 }
 
+// One-pass associative scan (gae_onepass_kernel): super-chunks of kOpW chunks of kOpL steps.
+constexpr unsigned kOpMaxSupers = kOnePassMaxSupers;   // every workgroup applies all earlier super-chunk maps itself: the list lives in LDS
+std::atomic<unsigned> g_onepass_serial{0};
+
+unsigned onepass_supers(const ppo_xp *h, size_t len) {
+  const size_t L = (size_t)h->op_l, W = (size_t)h->op_w;
+  return (unsigned)((((len + L - 1) / L) + W - 1) / W);
+}
+
+template <bool PACK>
+bool launch_onepass_shape(ppo_xp *h, const OnePassArgs &o, unsigned blocks) {
+  const long L = h->op_l, W = h->op_w;
+#define PPOXP_OP(LL, WW) if (L == LL && W == WW) { hipLaunchKernelGGL((gae_onepass_kernel<PACK, LL, WW>), dim3(blocks), dim3(64 * WW), 0, h->stream, o); return true; }
+  PPOXP_OP(64, 8) PPOXP_OP(64, 4) PPOXP_OP(64, 2) PPOXP_OP(32, 8) PPOXP_OP(32, 4) PPOXP_OP(32, 16) PPOXP_OP(16, 16) PPOXP_OP(16, 8)
+#undef PPOXP_OP
+  return false;
+}
+
+// PPO_XP_GAE_ASSOC without a forced chunk length takes the one-pass kernel when the list of earlier super-chunks every
+// workgroup walks stays short (len <= 64 * 8 * 64 = 32 768 steps); "gae_onepass" 0 / 1 forces the choice.
+bool onepass_wanted(const ppo_xp *h, int algo, size_t len) {
+  if (h->gae_onepass == 0) return false;
+  if ((((unsigned)algo >> 16) & 0xffffu) != 0) return false;          // the caller chose a chunk length: three-kernel scan
+  return onepass_supers(h, len) <= kOpMaxSupers;
+}
+
+int launch_gae_onepass(ppo_xp *h, GaeArgs a, bool pack, float *static_scratch) {
+  const size_t N = h->N;
+  const unsigned S = onepass_supers(h, a.len), groups = (unsigned)((N + 63) / 64);
+  const size_t words = (size_t)S * N * 2;
+  OnePassArgs o{};
+  if (static_scratch) {
+    if (words > kScratchOnePassWords)
+      return fail(PPO_XP_EINVAL, "returns_noalloc: %u super-chunks x %zu envs need %zu tagged words, the static scratch holds %zu",
+                  S, N, words, kScratchOnePassWords);
+    o.words = reinterpret_cast<unsigned long long *>(static_scratch + 3 * kScratchPairs);
+  } else {
+    if (words > h->op_cap) {
+      if (h->op_words) { HIP_TRY(hipStreamSynchronize(h->stream)); dev_free(h->op_words); h->op_cap = 0; }
+      if (int rc = dev_alloc(&h->op_words, words + 8, true)) return rc;     // zeroed: tag 0 is never used
+      h->op_cap = words;
+    }
+    o.words = h->op_words;
+  }
+  const size_t cap = static_scratch ? kScratchOnePassWords : h->op_cap;
+  o.ticket = o.words + cap;
+  o.err = reinterpret_cast<unsigned *>(o.words + cap + 1);
+  unsigned serial = ++g_onepass_serial;
+  if (serial == 0) serial = ++g_onepass_serial;
+  o.a = a; o.serial = serial; o.S = S; o.groups = groups;
+  o.a.chunk = (unsigned)h->op_l;
+  if ((size_t)S * groups > 0x7fffffffull) return fail(PPO_XP_EINVAL, "returns: too many workgroups for the one-pass scan");
+  ProfScope ps(h, PPO_XP_K_GAE);
+  if (!(pack ? launch_onepass_shape<true>(h, o, S * groups) : launch_onepass_shape<false>(h, o, S * groups)))
+    return fail(PPO_XP_EINVAL, "one-pass scan: no kernel for op_l = %ld, op_w = %ld", h->op_l, h->op_w);
+  if (int rc = launch_check("gae_onepass_kernel")) return rc;
+  h->op_err_pending = o.err;
+  return 0;
+}
+
+// A look-back of the one-pass scan that gave up (never seen; the bound exists so that a bug cannot hang the GPU) is
+// reported by the next call that waits for the stream anyway.
+int onepass_check(ppo_xp *h) {
+  if (!h->op_err_pending) return 0;
+  unsigned flag = 0;
+  unsigned *p = h->op_err_pending;
+  h->op_err_pending = nullptr;
+  HIP_TRY(hipMemcpyAsync(&flag, p, sizeof(flag), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  if (flag) {
+    (void)hipMemsetAsync(p, 0, sizeof(flag), h->stream);
+    return fail(PPO_XP_EIO, "one-pass GAE scan: a workgroup gave up waiting for an earlier chunk's carry map; results are invalid");
+  }
+  return 0;
+}
+
 // Chunk length and count of the associative scan for `len` time steps (bits 16..31 of algo force the length).
 void gae_chunking(const ppo_xp *h, int algo, size_t len, unsigned &L_out, unsigned &chunks_out) {
   unsigned L = ((unsigned)algo >> 16) & 0xffffu;
@@ -334,6 +415,11 @@ int run_gae(ppo_xp *h, int algo, bool want_flat, float *static_scratch = nullptr
   a.gl = h->gamma * h->lambda;  // one fp32 product, computed first (buffer.rs:219)
   unsigned chunks = 1;
   a.chunk = (unsigned)len;
+  if (kind == PPO_XP_GAE_ASSOC && onepass_wanted(h, algo, len)) {
+    if (int rc = launch_gae_onepass(h, a, pack, static_scratch)) return rc;
+    h->have_returns = true; h->have_rec = pack; h->have_flat = a.flat != 0; h->ret_len = len;
+    return 0;
+  }
   if (kind == PPO_XP_GAE_ASSOC) gae_chunking(h, algo, len, a.chunk, chunks);
   if (chunks > 1) {
     const size_t need = (size_t)chunks * N;
@@ -883,7 +969,7 @@ void ppo_xp_destroy(ppo_xp *h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   dev_free(h->obs); dev_free(h->rewards); dev_free(h->actions); dev_free(h->values); dev_free(h->dones);
   dev_free(h->neglogps); dev_free(h->returns); dev_free(h->adv); dev_free(h->rec); dev_free(h->done_bits); dev_free(h->perm);
-  dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ);
+  dev_free(h->carry); dev_free(h->sumP); dev_free(h->sumQ); dev_free(h->op_words);
   dev_free(h->obs_out); dev_free(h->act_out); dev_free(h->val_out); dev_free(h->nlp_out); dev_free(h->ret_out);
   dev_free(h->adv_out); dev_free(h->partials); dev_free(h->sums); dev_free(h->stats);
   dev_free(h->moments);
@@ -1071,7 +1157,13 @@ static int returns_impl(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo
   if (static_scratch && kind == PPO_XP_GAE_ASSOC && buf_len(h)) {   // refuse BEFORE anything changes: the call then does nothing
     unsigned L = 0, chunks = 1;
     gae_chunking(h, algo, buf_len(h), L, chunks);
-    if (chunks > 1 && (size_t)chunks * h->N > kScratchPairs)
+    if (onepass_wanted(h, algo, buf_len(h))) {
+      const size_t words = (size_t)onepass_supers(h, buf_len(h)) * h->N * 2;
+      if (words > kScratchOnePassWords)
+        return fail(PPO_XP_EINVAL, "returns_noalloc: %u super-chunks x %zu envs need %zu tagged words, the static scratch holds %zu "
+                    "(choose a chunk length with PPO_XP_GAE_CHUNK for the three-kernel scan, or ppo_xp_returns)",
+                    onepass_supers(h, buf_len(h)), h->N, words, kScratchOnePassWords);
+    } else if (chunks > 1 && (size_t)chunks * h->N > kScratchPairs)
       return fail(PPO_XP_EINVAL, "returns_noalloc: %u chunks x %zu envs = %zu chunk maps, the static scratch holds %zu "
                   "(use fewer, longer chunks with PPO_XP_GAE_CHUNK, or ppo_xp_returns)", chunks, h->N, (size_t)chunks * h->N, kScratchPairs);
   }
@@ -1095,6 +1187,7 @@ static int returns_impl(ppo_xp *h, const uint8_t *last_dones, size_t n, int algo
     const size_t M = buf_len(h) * h->N;
     if (M) HIP_TRY(hipMemcpyAsync(host_out, h->returns, M * sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (int rc = onepass_check(h)) return rc;
   }
   return 0;
 }
@@ -1488,7 +1581,7 @@ int ppo_xp_sync(ppo_xp *h) {
   if (!h) return fail(PPO_XP_EINVAL, "sync: handle is NULL");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
-  return 0;
+  return onepass_check(h);
 }
 
 int ppo_xp_device(const ppo_xp *h) { return h ? h->device : -1; }
@@ -1534,6 +1627,9 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
   else if (n == "scalar_path" && (value == 0 || value == 1)) h->scalar_path = value;
 #endif
   else if (n == "bij_mode" && value >= 0 && value <= 2) h->bij_mode = value;
+  else if (n == "gae_onepass" && value >= -1 && value <= 1) h->gae_onepass = value;
+  else if (n == "op_l" && (value == 16 || value == 32 || value == 64)) h->op_l = value;
+  else if (n == "op_w" && (value == 2 || value == 4 || value == 8 || value == 16)) h->op_w = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;
   else if (n == "out_nt" && (value == 0 || value == 1)) h->out_nt = value;
   else if (n == "gae_unroll" && (value == 0 || value == 4 || value == 8 || value == 16 || value == 32)) h->gae_unroll = value;

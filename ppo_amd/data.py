@@ -172,13 +172,19 @@ class ExperienceBatcherIterator:
         import torch
         buf = self.batcher.buffer
         v = _lib.BatchView()
+        hs = None
+        if buf.streaming:
+            # the call enqueues minibatch k's gather into slot k % 2 on the handle's stream: it must run after whatever
+            # torch's current stream still does with that slot (the consumer's work on minibatch k - 2) ...
+            cur, hs = buf._order_streams()
+            if hs is not None:
+                hs.wait_stream(cur)
         rc = check(self.batcher._L.ppo_xp_pass_next(buf.handle, C.byref(v)))
         if rc == 1:
             raise StopIteration
         if buf.streaming:
-            # this very call enqueued minibatch k's kernels on the handle's stream: order torch's current stream behind
-            # them (no host wait, so the consumer's work on k overlaps the gather of k+1)
-            cur, hs = buf._order_streams()
+            # ... and torch's stream must see the minibatch: stream-to-stream, no host wait, so the consumer's work
+            # on k overlaps the gather of k + 1
             if hs is not None:
                 cur.wait_stream(hs)
         elif v.index == 0:

@@ -1,0 +1,111 @@
+"""The associative GAE scan in ONE launch (gae_onepass_kernel; replaces buffer.rs:187-225 for long horizons): every
+chunk is read once and kept in registers, the chunk maps cross workgroups as tagged 64-bit words inside the running grid.
+Through the C ABI:
+  * within the stated K2 bound (1e-5 relative to max(1, |ret|)) of the bit-exact sequential kernel and of the oracle,
+    for ragged lengths (below one chunk, not a multiple of a chunk, more than one super-chunk), ragged env counts,
+    wrapped rings, both output forms (records / flat arrays);
+  * deterministic: two calls give the same bits (the carries are applied in a fixed order, whatever the timing);
+  * the three-kernel scan (tunable gae_onepass = 0, or a forced chunk length) still answers, within the same bound;
+  * the allocation-free entry point runs it from the static scratch, same bits, and refuses what does not fit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_gpu_parity import bits, both
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def xp():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import ppo_amd
+    return ppo_amd
+
+
+def _close(a, ref):
+    return np.all(np.abs(a - ref) <= RTOL * np.maximum(1.0, np.abs(ref)))
+
+
+@pytest.mark.parametrize("T,N,cap,p_done", [(1, 5, 1, 0.1), (63, 64, 63, 0.05), (64, 130, 64, 0.0), (65, 64, 65, 0.05), (511, 70, 511, 0.02),
+                                            (512, 64, 512, 0.02), (513, 33, 513, 0.3), (1500, 200, 1500, 0.01), (700, 64, 300, 0.05)])
+def test_onepass_against_sequential_and_oracle(xp, oracle, T, N, cap, p_done):
+    g, o, r = both(xp, oracle, T, N, 2, cap, seed=T + N, p_done=p_done, bulk=True)
+    ld = r["last_dones"]
+    want = o.returns(ld)
+    seq = g.returns(ld, algo=xp.GAE_SEQUENTIAL, to_host=True)
+    np.testing.assert_array_equal(bits(seq), bits(want))
+    one = g.returns(ld, algo=xp.GAE_ASSOC, to_host=True)                      # records + flat arrays
+    assert _close(one, want)
+    again = g.returns(ld, algo=xp.GAE_ASSOC, to_host=True)
+    np.testing.assert_array_equal(bits(one), bits(again))                      # deterministic
+    flat = g.returns(ld, algo=xp.GAE_ASSOC | xp.GAE_NO_PACK, to_host=True)
+    np.testing.assert_array_equal(bits(one), bits(flat))                       # same arithmetic, other output form
+    np.testing.assert_array_equal(bits(g.advantages().cpu().numpy()), bits(oracle.advantages(flat, o.training_views()[2])))
+    g.set_tunable("gae_onepass", 0)
+    three = g.returns(ld, algo=xp.GAE_ASSOC, to_host=True)
+    assert _close(three, want)
+    g.set_tunable("gae_onepass", -1)
+    # a pass on top of the records the one-pass scan wrote: returns gathered bit for bit
+    g.returns(ld, algo=xp.GAE_ASSOC)
+    M = len(o) * N
+    it = xp.ExperienceBatcher(g, max(1, M // 3)).into_iter(seed=5, bijection=True)
+    p = it.perm()
+    for (s, e), b in zip(oracle.batch_windows(M, max(1, M // 3)), it):
+        np.testing.assert_array_equal(bits(b.returns.cpu().numpy()), bits(one[p[s:e]]))
+    g.close()
+
+
+def test_onepass_special_values(xp, oracle):
+    """inf / NaN / denormal inputs travel through the maps like through the sequential scan (NaN stays NaN where it is)."""
+    from ppo_amd import synth
+    T, N = 300, 64
+    r = synth.rollout(T, N, 1, 4, 0.05)
+    r["rewards"][10, 3] = np.inf
+    r["rewards"][200, 5] = np.nan
+    r["values"][100, 7] = 1e-42
+    g = xp.ExperienceBuffer(N, 1, T)
+    g.add_many(r["obs"], r["rewards"], r["actions"], r["values"], r["dones"], r["neglogps"])
+    seq = g.returns(r["last_dones"], algo=xp.GAE_SEQUENTIAL, to_host=True)
+    one = g.returns(r["last_dones"], algo=xp.GAE_ASSOC, to_host=True)
+    fin = np.isfinite(seq)
+    assert np.array_equal(np.isnan(seq), np.isnan(one)) and np.array_equal(np.isinf(seq), np.isinf(one))
+    assert _close(one[fin], seq[fin])
+    g.close()
+
+
+def test_onepass_from_the_static_scratch_and_its_limit(xp):
+    import torch
+    from ppo_amd import _lib
+    L = _lib.load()
+    N, T = 16384, 8704                   # 136 chunks -> 17 super-chunks x 16384 envs x 2 words > 2^19
+    buf = xp.ExperienceBuffer(N, 1, T)
+    z = torch.zeros
+    row = (z(N, 1, device="cuda"), torch.randn(N, device="cuda"), z(N, dtype=torch.int64, device="cuda"), torch.randn(N, device="cuda"),
+           z(N, device="cuda"), z(N, device="cuda"))
+    for t in range(T):
+        buf.add_experience_device(*row)
+    buf.sync()
+    ld = np.zeros(N, np.uint8)
+    counter = buf._L.ppo_xp_counter(buf.handle)
+    rc = L.ppo_xp_returns_noalloc(buf.handle, ld.ctypes.data_as(C.c_void_p), N, _lib.GAE_ASSOC, None)
+    assert rc == _lib.EINVAL and "static scratch" in _lib.last_error()
+    assert buf._L.ppo_xp_counter(buf.handle) == counter
+    buf.close()
+    # what fits runs from the static scratch with the bits of the allocating entry point
+    N, T = 1024, 4096
+    buf = xp.ExperienceBuffer(N, 1, T)
+    row = tuple(t[:N] if t.dim() == 1 else t[:N] for t in row)
+    for t in range(T):
+        buf.add_experience_device(row[0], row[1] * (1 + t % 7), row[2], row[3], row[4], row[5])
+    buf.sync()
+    ld = np.zeros(N, np.uint8)
+    a = np.empty(T * N, np.float32)
+    b = np.empty(T * N, np.float32)
+    _lib.check(L.ppo_xp_returns(buf.handle, ld.ctypes.data_as(C.c_void_p), N, _lib.GAE_ASSOC, a.ctypes.data_as(C.c_void_p)))
+    _lib.check(L.ppo_xp_returns_noalloc(buf.handle, ld.ctypes.data_as(C.c_void_p), N, _lib.GAE_ASSOC, b.ctypes.data_as(C.c_void_p)))
+    np.testing.assert_array_equal(bits(a), bits(b))
+    buf.close()
