@@ -403,6 +403,19 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     return res, (T, N, D, K, gae_only)
 
 
+def cited_traffic(config, kernel, perm):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/gather_traffic.json): a citation of
+    a separate counter run of the same kernel on the same config, not a measurement of this run (counters need their own
+    rocprofv3 passes)."""
+    try:
+        for tf in json.load(open(os.path.join(ROOT, "profiles", "gather_traffic.json"))):
+            if tf.get("config") == config and tf.get("kernel") == kernel and tf.get("perm") in (perm, "none"):
+                return {"traffic": tf.get("hbm_bytes_per_launch"), "traffic_source": tf.get("source")}
+    except Exception:
+        pass
+    return {}
+
+
 def copy_ceiling(dev, nbytes=1 << 30, reps=10):
     """The box's stream-copy rate (reported for context, the fraction stays against 8 TB/s):
     device-to-device copy of 1 GiB, read + write bytes counted, torch events on the current stream."""
@@ -505,15 +518,7 @@ def main():
                "scaling": res.pop("scaling"), "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
         res.pop("steps"); res.pop("warmup")
         out.update(res)
-        traffic_file = os.path.join(ROOT, "profiles", "gather_traffic.json")
-        if os.path.exists(traffic_file):
-            try:
-                tf = json.load(open(traffic_file))
-                if tf.get("config") == args.config and tf.get("kernel") == out["roofline"]["kernel"]:
-                    out["roofline"]["traffic"] = tf.get("hbm_bytes_per_launch")
-                    out["roofline"]["traffic_source"] = tf.get("source")
-            except Exception:
-                pass
+        out["roofline"].update(cited_traffic(args.config, out["roofline"]["kernel"], args.perm))
 
     # ---- the other BASELINE.json configs beside the headline, measured the same way ---------------
     if args.config == "TGT" and not args.no_secondary:
@@ -531,6 +536,9 @@ def main():
             try:
                 r2, _ = measure(ctx, cfg, st, wu, events=False, breakdown=(cfg != "C2"), exchange=xch)
                 r2.pop("roofline", None)
+                tr = cited_traffic(cfg, "gae_scan_kernel" if cfg == "C4" else "obs_gather_kernel", args.perm)
+                if tr:
+                    r2["dominant_kernel_traffic"] = tr
                 also[cfg if xch is None else f"{cfg}_exchange_{xch}"] = r2
             except Exception as e:
                 if world > 1:           # a rank that gives up alone would leave the others inside a collective

@@ -41,12 +41,18 @@ def main():
     L, h = _lib.load(), buf.handle
     ldp = ld.ctypes.data_as(C.c_void_p)
     _lib.check(L.ppo_xp_returns(h, ldp, N, algo, None))
-    _lib.check(L.ppo_xp_pass_begin(h, B, None, 1))
-    perm = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, 0, buf).clone()
-    buf.sync()
-    for _ in range(steps):
-        _lib.check(L.ppo_xp_returns(h, ldp, N, algo, None))
-        _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
+    if os.environ.get("PPO_XP_PERM", "bijection") == "bijection":   # what bench.py times: the keyed bijection inside the step
+        for i in range(steps):
+            _lib.check(L.ppo_xp_returns(h, ldp, N, algo, None))
+            if B < M or M:
+                _lib.check(L.ppo_xp_pass_begin_bijection(h, B, 100 + i))
+    else:
+        _lib.check(L.ppo_xp_pass_begin(h, B, None, 1))
+        perm = ppo_amd.device_tensor(L.ppo_xp_pass_perm_device(h), (M,), torch.uint32, 0, buf).clone()
+        buf.sync()
+        for _ in range(steps):
+            _lib.check(L.ppo_xp_returns(h, ldp, N, algo, None))
+            _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
     buf.sync()
     buf.close()
 
