@@ -838,8 +838,12 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   const unsigned FBq = (unsigned)h->fused_block;
   const unsigned rpw = (Dq && FBq % Dq == 0) ? FBq / Dq : 0u;
   const bool fits_mall = rec_halves(M) * sizeof(Rec) <= (size_t(160) << 20);
+  // A keyed-bijection pass has no index stream: with 256-byte rows (32+ rows per workgroup) the fused kernel then wins or
+  // ties at every size measured - per-GPU shard of C5 at 8 ranks (268 MB of records) 1 793 us against 1 909, at 4 / 2 / 1
+  // ranks +0.8 / +0.3 / 0 % - while with 1-KiB rows (C3) it still loses 9 % (profiles/r3/ab_bijection_sizes.log).
+  const bool bij_fused = h->pass_bij && h->bij_mode != 0 && rpw >= 32;
   const bool fusable = h->fused != 0 && h->D % 4 == 0 && (Dq & (Dq - 1)) == 0 && rpw >= 8 && rpw <= 64 &&
-                       B % rpw == 0 && K <= 65535 && (h->fused == 1 || fits_mall);
+                       B % rpw == 0 && K <= 65535 && (h->fused == 1 || fits_mall || bij_fused);
   const size_t tile_rows = fusable ? rpw : 256;
   if (int rc = ensure_pass_buffers(h, K, B, tile_rows)) return rc;
   if (!h->have_rec) {
