@@ -121,14 +121,15 @@ class ShardedBatcher:
                 torch.cuda.current_stream(self.buffer.device).synchronize()
         self.buffer.pass_finish()
 
-    def into_iter(self, seed=None, perm=None) -> ExperienceBatcherIterator:
-        """One sharded pass: local gather + local sums, the exchange, local standardisation."""
+    def into_iter(self, seed=None, perm=None, bijection: bool = False) -> ExperienceBatcherIterator:
+        """One sharded pass: local gather + local sums, the exchange, local standardisation.  bijection=True: every rank's
+        local permutation is the keyed bijection of its rank seed, evaluated inside the gather (no index array)."""
         if seed is None and perm is None:
             seed = self._seed
             self._seed += 1
         if seed is not None:
             seed = rank_seed(seed, self.rank)
-        it = self._batcher.into_iter(seed=seed, perm=perm)
+        it = self._batcher.into_iter(seed=seed, perm=perm, bijection=bijection)
         self.exchange()
         return it
 

@@ -75,7 +75,7 @@ def test_exchange_modes_agree_on_one_rank(T, N, D, B, overlap):
             assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
 
 
-def _rank(rank, world, port, T, N, D, B, seed, q):
+def _rank(rank, world, port, T, N, D, B, seed, q, bijection=False):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -94,9 +94,9 @@ def _rank(rank, world, port, T, N, D, B, seed, q):
                               full["last_dones"], 0.99, 0.95).reshape(T, N)
         assert np.array_equal(ret.view(np.uint32), np.ascontiguousarray(ret_full[:, sl]).reshape(-1).view(np.uint32))
         sb = sharded.ShardedBatcher(buf, B, seed=seed)
-        it = sb.into_iter(seed=seed)
+        it = sb.into_iter(seed=seed, bijection=bijection)
         perm = it.perm()
-        assert np.array_equal(perm, O.shuffle(sharded.rank_seed(seed, rank), T * n))
+        assert np.array_equal(perm, (O.bijection_perm if bijection else O.shuffle)(sharded.rank_seed(seed, rank), T * n))
         batches = list(it)
         Bl = sb.local_batch
         adv_loc = O.advantages(ret, np.ascontiguousarray(full["values"][:, sl]).reshape(-1))
@@ -139,12 +139,14 @@ def _rank(rank, world, port, T, N, D, B, seed, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_over_gloo():
+@pytest.mark.parametrize("shape,bijection", [((20, 64, 16, 256), False), ((16, 256, 64, 1024), True)])
+def test_two_ranks_on_one_gpu_over_gloo(shape, bijection):
+    """Second case: every rank's permutation is the keyed bijection of its rank seed, evaluated inside the fused gather."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, 20, 64, 16, 256, 4242, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, 2, port) + shape + (4242, q, bijection)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
