@@ -458,6 +458,7 @@ def main():
     ap.add_argument("--tunable", action="append", default=[], help="name=value (see ppo_xp_set_tunable)")
     ap.add_argument("--streaming", action="store_true", help="gather minibatches one at a time into two slots (ppo_xp_set_streaming): "
                                                               "half the memory of a pass; not with --gpus > 1")
+    ap.add_argument("--secondary-timeout", type=float, default=240.0, help="seconds the configs under 'also' may take before the headline is printed alone")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -523,6 +524,21 @@ def main():
     # ---- the other BASELINE.json configs beside the headline, measured the same way ---------------
     if args.config == "TGT" and not args.no_secondary:
         also = {}
+        # The headline is measured; nothing after it may cost it.  A secondary leg that raises is caught below; one that
+        # HANGS (a collective some rank never enters) cannot be caught, so every rank arms the same timer: when it fires,
+        # rank 0 prints the line with what it has and every rank leaves.
+        import threading
+
+        def _bail(why=None):
+            why = why or f"secondary configs did not finish within {args.secondary_timeout} s"
+            log(f"bench.py: rank {rank}: {why}; reporting the headline alone")
+            if rank == 0 and out is not None:
+                out["also"] = dict(also, error=why)
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            os._exit(0)
+        watchdog = threading.Timer(args.secondary_timeout, _bail)
+        watchdog.daemon = True
+        watchdog.start()
         # one GPU: configs[1] C2, configs[2] C3, configs[3] C4 (GAE only, K2 + its error against K1) and C5 whole on
         # this GPU (= the per-GPU shard of a 1-rank job); N GPUs: C5 split over the ranks (strong scaling)
         todo = [("C5", 10, 3, None)] if world > 1 else [("C3", 12, 3, None), ("C5", 10, 3, None), ("C2", 200, 20, None), ("C4", 100, 10, None)]
@@ -541,12 +557,15 @@ def main():
                     r2["dominant_kernel_traffic"] = tr
                 also[cfg if xch is None else f"{cfg}_exchange_{xch}"] = r2
             except Exception as e:
-                if world > 1:           # a rank that gives up alone would leave the others inside a collective
-                    raise
-                # one GPU: a secondary line must never cost the headline
-                log(f"bench.py: secondary config {cfg} failed: {type(e).__name__}: {e}")
-                also[cfg] = {"error": f"{type(e).__name__}: {e}"}
+                # a secondary line must never cost the headline.  Several ranks: the others may sit inside a collective this
+                # rank never reaches - stop the secondaries here and let the timer release whoever is stuck
+                log(f"bench.py: secondary config {cfg} failed on rank {rank}: {type(e).__name__}: {e}")
+                also[cfg if xch is None else f"{cfg}_exchange_{xch}"] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()
+                if world > 1:
+                    watchdog.cancel()
+                    _bail(f"secondary config {cfg} failed on rank {rank}")     # leaves; the other ranks' timers release them
+        watchdog.cancel()
         if out is not None:
             out["also"] = also
 
