@@ -114,6 +114,14 @@ class ExperienceBatcher {
       b.index = io.index;
       return true;
     }
+    // the same with the download of minibatch k+1 overlapping the caller's work on k (ppo_xp_pass_next_host_pipelined):
+    // `cur` receives minibatch k, `next_slot` must stay untouched until it is passed as `cur`; alternate two batches
+    bool next_host_pipelined(HostExperienceBatch<OBS_SIZE> &cur, HostExperienceBatch<OBS_SIZE> &next_slot) {
+      ppo_batch_host a = slot(cur), b = slot(next_slot);
+      if (check(ppo_xp_pass_next_host_pipelined(h_, &a, &b)) != 0) return false;
+      cur.index = a.index;
+      return true;
+    }
     std::vector<uint32_t> perm() const {
       ppo_xp_views_t v; check(ppo_xp_views(h_, &v));
       std::vector<uint32_t> p(v.num_steps);
@@ -123,6 +131,18 @@ class ExperienceBatcher {
    private:
     friend class ExperienceBatcher;
     Iter(ppo_xp *h, size_t batch_size) : h_(h), batch_size_(batch_size) {}
+    ppo_batch_host slot(HostExperienceBatch<OBS_SIZE> &b) const {
+      if (b.values.size() != batch_size_) {      // sized once: the arrays must not move while a download is in flight
+        b.observations.resize(batch_size_); b.actions.resize(batch_size_); b.values.resize(batch_size_);
+        b.neglogps.resize(batch_size_); b.returns.resize(batch_size_); b.advantages.resize(batch_size_);
+      }
+      ppo_batch_host io{};
+      io.capacity = batch_size_;
+      io.observations = batch_size_ ? b.observations[0].data() : nullptr; io.actions = b.actions.data();
+      io.values = b.values.data(); io.neglogps = b.neglogps.data(); io.returns = b.returns.data();
+      io.advantages = b.advantages.data();
+      return io;
+    }
     ppo_xp *h_;
     size_t batch_size_;
     ExperienceBatch cur_{};
@@ -140,6 +160,11 @@ class ExperienceBatcher {
   // the permutation drawn on the device (no host Fisher-Yates on the critical path)
   Iter into_iter_device_shuffle(uint64_t seed) {
     check(ppo_xp_pass_begin_device_shuffle(buf_.handle(), batch_size_, seed));
+    return Iter(buf_.handle(), batch_size_);
+  }
+  // the permutation as a keyed bijection of (seed, len()) evaluated inside the gather: no index array at all
+  Iter into_iter_bijection(uint64_t seed) {
+    check(ppo_xp_pass_begin_bijection(buf_.handle(), batch_size_, seed));
     return Iter(buf_.handle(), batch_size_);
   }
   // start drawing the Fisher-Yates of a coming into_iter(seed) on a worker thread

@@ -160,6 +160,28 @@ static void batcher_host_batches() {
   io.returns = f.data(); io.advantages = f.data();
   EXPECT(ppo_xp_pass_next_host(buf.handle(), &io) == PPO_XP_EINVAL);
   EXPECT(it2.next() != nullptr && it2.next() != nullptr && it2.next() == nullptr);
+  // data.rs:91-102 with the permutation as a keyed bijection evaluated inside the gather, and the hand-off of
+  // training.rs:205-207 overlapped: two host batches alternate, k+1 downloads while k is looked at
+  auto it3 = batcher.into_iter_bijection(99);
+  auto perm3 = it3.perm();
+  std::vector<int> seen(10, 0);
+  for (uint32_t p : perm3) { EXPECT(p < 10); if (p < 10) seen[p]++; }
+  for (int c : seen) EXPECT(c == 1);                       // a permutation of 0..10
+  HostExperienceBatch<3> slots[2];
+  k = 0;
+  while (it3.next_host_pipelined(slots[k & 1], slots[(k + 1) & 1])) {
+    const HostExperienceBatch<3> &b = slots[k & 1];
+    EXPECT(b.index == k);
+    const size_t start = k == 0 ? 0 : 4;
+    for (size_t j = 0; j < 6; ++j) {
+      const uint32_t p = perm3[start + j];
+      for (int c = 0; c < 3; ++c) EXPECT(b.observations[j][c] == obs0[3 * p + c]);
+      EXPECT(b.returns[j] == ret[p]);
+      EXPECT(b.actions[j] == ((p & 1) ? (size_t(1) << 40) : size_t(1 + p / 2)));
+    }
+    ++k;
+  }
+  EXPECT(k == 2);
 }
 
 int main() {
