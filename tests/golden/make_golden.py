@@ -30,8 +30,26 @@ def make(path, T, N, D, B, seed, p_done):
     print(path, os.path.getsize(path), "bytes, K =", out["K"])
 
 
+def make_bijection(path):
+    """Vectors of the keyed bijection (ppo_xp_pass_begin_bijection; no counterpart in the reference, whose shuffle is
+    OS-seeded): whole permutations for small M, heads and CRC-32 checksums of the whole array for large M.  Written from the
+    oracle's C twin; the numpy twin and the library are compared against the same file."""
+    import json
+    import zlib
+    cases = []
+    for seed, M in [(0, 1), (1, 2), (7, 5), (0x5EED, 257), (2**64 - 1, 1000), (42, 65536), (99, 1 << 23), (123456789, 1010707)]:
+        p = O.bijection_perm(seed, M)
+        q = O.bijection_perm(seed, M, inverse=True)
+        cases.append({"seed": str(seed), "M": M, "head": p[:16].tolist(), "tail": p[-4:].tolist(),
+                      "crc32": zlib.crc32(p.tobytes()), "inverse_head": q[:8].tolist(),
+                      "all": p.tolist() if M <= 1000 else None})
+    json.dump({"spec": "ppo_amd/csrc/bijection.h", "indices": "uint32 little endian", "cases": cases}, open(path, "w"))
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
+    make_bijection(os.path.join(here, "bijection_kats.json"))
     T, N, D, B = synth.CONFIGS["C1"]
     make(os.path.join(here, "c1_path.npz"), T, N, D, B, synth.SEEDS["C1"], 0.02)
     # ragged: N not a multiple of 64, D = 3 (scalar gather path), B does not divide M (overlapping tail)

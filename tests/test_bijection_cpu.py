@@ -77,3 +77,19 @@ def test_large_permutation_looks_shuffled():
     np.add.at(tab, (p[:-1] & 15, p[1:] & 15), 1)
     exp = (M - 1) / 256
     assert abs(((tab - exp) ** 2 / exp).sum() - 255) < 6 * np.sqrt(2 * 255)
+
+
+def test_committed_vectors():
+    """tests/golden/bijection_kats.json (written by tests/golden/make_golden.py from the C twin): both twins still give them."""
+    import json
+    import os
+    import zlib
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bijection_kats.json")))
+    for c in kats["cases"]:
+        seed, M = int(c["seed"]), c["M"]
+        for fn in (O.bijection_perm, O.np_bijection_perm):
+            p = fn(seed, M)
+            assert p[:16].tolist() == c["head"] and p[-4:].tolist() == c["tail"] and zlib.crc32(p.tobytes()) == c["crc32"]
+            if c["all"] is not None:
+                assert p.tolist() == c["all"]
+        assert O.bijection_perm(seed, M, inverse=True)[:8].tolist() == c["inverse_head"]

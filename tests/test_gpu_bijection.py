@@ -163,3 +163,24 @@ def test_pipelined_host_handoff_matches_the_oracle(xp, oracle, T, N, D, B, bijec
     with pytest.raises(xp.PpoXpError):
         next(it.host_batches())
     g.close()
+
+
+def test_library_gives_the_committed_vectors(xp):
+    """tests/golden/bijection_kats.json: whole arrays for small M, head / tail / CRC-32 of the whole array for 2^23 and 1 010 707."""
+    import json
+    import os
+    import zlib
+    import torch
+    kats = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bijection_kats.json")))
+    shapes = {1: (1, 1), 2: (1, 2), 5: (1, 5), 257: (1, 257), 1000: (10, 100), 65536: (16, 4096), 1 << 23: (128, 65536), 1010707: (101, 10007)}
+    z = torch.zeros
+    for c in kats["cases"]:
+        T, N = shapes[c["M"]]
+        buf = xp.ExperienceBuffer(N, 4, T)
+        for t in range(T):
+            buf.add_experience_device(z(N, 4, device="cuda"), z(N, device="cuda"), z(N, dtype=torch.int64, device="cuda"),
+                                      z(N, device="cuda"), z(N, device="cuda"), z(N, device="cuda"))
+        buf.returns(np.zeros(N, np.uint8))
+        p = xp.ExperienceBatcher(buf, max(1, c["M"] // 2)).into_iter(seed=int(c["seed"]), bijection=True).perm()
+        assert p[:16].tolist() == c["head"] and p[-4:].tolist() == c["tail"] and zlib.crc32(p.tobytes()) == c["crc32"]
+        buf.close()
