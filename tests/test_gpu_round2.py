@@ -338,3 +338,28 @@ def test_device_insert_single_launch(xp, oracle, N, D, cap, steps, offset):
     M = len(o) * N
     check_pass(xp, oracle, g, o, r["last_dones"], max(1, M // 3), seed=5)
     g.close()
+
+
+def test_streamed_pass_guards(xp, oracle):
+    """Round-3 advisor items: a streamed pass knows minibatch k's statistics only once pass_next has gathered it
+    (ESTATE before the pass is exhausted), and a tunable changed in the middle of a streamed pass ends that pass
+    (its launch shapes - tiles, partials - were fixed at pass_begin)."""
+    g, o, r = _both(xp, oracle, 8, 128, 64, 5)
+    g.returns(r["last_dones"])
+    g.set_streaming(True)
+    it = xp.ExperienceBatcher(g, 256).into_iter(seed=3)
+    next(it)
+    with pytest.raises(xp.PpoXpError) as e:
+        it.stats()
+    assert e.value.code == -1
+    rest = list(it)
+    assert len(rest) == 3 and it.stats().shape == (4, 2)
+    it = xp.ExperienceBatcher(g, 256).into_iter(seed=3)
+    next(it)
+    g.set_tunable("fused_block", 256)
+    with pytest.raises(xp.PpoXpError) as e:
+        next(it)
+    assert e.value.code == -1                      # no pass any more: begin again
+    g.set_tunable("fused_block", 512)
+    assert len(list(xp.ExperienceBatcher(g, 256).into_iter(seed=3))) == 4
+    g.close()
