@@ -508,18 +508,22 @@ def main():
     res, (T, N, D, K, gae_only) = measure(ctx, args.config, args.steps, args.warmup, gae=args.gae,
                                           events=not args.no_kernel_events, tunables=args.tunable)
 
-    out = None
-    if rank == 0:
+    def headline(res):
+        """The contract's line from one measure() result of the headline config."""
+        res = dict(res)
         try:
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             metric = "transitions/sec through GAE+norm+minibatch gather; % of HBM roofline, 1–8 GPU"
-        out = {"metric": metric, "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
-               "scaling": res.pop("scaling"), "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
+        line = {"metric": metric, "value": res.pop("value"), "unit": res.pop("unit"), "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": res.pop("ms_per_step"), "higher_is_better": True,
+                "scaling": res.pop("scaling"), "vs_baseline": None, "dtype": "f32", "data": "synthetic"}
         res.pop("steps"); res.pop("warmup")
-        out.update(res)
-        out["roofline"].update(cited_traffic(args.config, out["roofline"]["kernel"], args.perm))
+        line.update(res)
+        line["roofline"].update(cited_traffic(args.config, line["roofline"]["kernel"], args.perm))
+        return line
+
+    out = headline(res) if rank == 0 else None
 
     # ---- the other BASELINE.json configs beside the headline, measured the same way ---------------
     if args.config == "TGT" and not args.no_secondary:
@@ -550,6 +554,10 @@ def main():
                 todo.insert(0, ("TGT", args.steps, args.warmup, other))
         for cfg, st, wu, xch in todo:
             try:
+                if xch is not None:       # the headline config under the other exchange: measured exactly like the headline
+                    r2, _ = measure(ctx, cfg, st, wu, gae=args.gae, events=not args.no_kernel_events, tunables=args.tunable, exchange=xch)
+                    also[f"{cfg}_exchange_{xch}"] = r2
+                    continue
                 r2, _ = measure(ctx, cfg, st, wu, events=False, breakdown=(cfg != "C2"), exchange=xch)
                 r2.pop("roofline", None)
                 tr = cited_traffic(cfg, "gae_scan_kernel" if cfg == "C4" else "obs_gather_kernel", args.perm)
@@ -567,6 +575,20 @@ def main():
                     _bail(f"secondary config {cfg} failed on rank {rank}")     # leaves; the other ranks' timers release them
         watchdog.cancel()
         if out is not None:
+            # Two implementations of the one exchange were timed on the same workload in this run (the caller's torch.distributed
+            # all-reduce and the library's own ncclAllReduce on the pass's stream): the line reports the faster one and keeps
+            # the other under "also"; config.exchange names which is which.
+            for key in [k for k in also if k.startswith("TGT_exchange_")]:
+                r2 = also[key]
+                if "ms_per_step" in r2 and r2["ms_per_step"] < out["ms_per_step"]:
+                    loser = {k: v for k, v in out.items() if k not in ("metric", "n_gpus", "higher_is_better", "vs_baseline", "dtype", "data")}
+                    out = headline(r2)
+                    del also[key]
+                    also["TGT_exchange_" + loser["config"]["exchange"].split("/")[0]] = loser
+                    out["headline_choice"] = "the faster of the two exchanges timed in this run; the other one is under also." \
+                                             "TGT_exchange_" + loser["config"]["exchange"].split("/")[0]
+                else:
+                    r2.pop("roofline", None)
             out["also"] = also
 
     if multi:

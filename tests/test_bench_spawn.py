@@ -109,7 +109,13 @@ def test_one_rank_rccl_line_runs_both_exchanges():
                        capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')][0])
-    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["config"]["exchange"] == "torch/nccl"
-    other = out["also"]["TGT_exchange_rccl"]
-    assert other["rccl_ranks"] == 1 and other["config"]["exchange"] == "rccl/nccl"
-    assert other["exchange_exposed_us"] is not None
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1
+    # both exchanges were timed on TGT; the line reports the faster one and keeps the other under "also"
+    mine = out["config"]["exchange"]
+    assert mine in ("torch/nccl", "rccl/nccl")
+    other_key = "TGT_exchange_rccl" if mine == "torch/nccl" else "TGT_exchange_torch"
+    other = out["also"][other_key]
+    assert other["rccl_ranks"] == 1 and other["config"]["exchange"] == ("rccl/nccl" if mine == "torch/nccl" else "torch/nccl")
+    assert other["exchange_exposed_us"] is not None and out["exchange_exposed_us"] is not None
+    assert out["ms_per_step"] <= other["ms_per_step"]
+    assert "roofline" in out and out["roofline"]["frac"] > 0.5
