@@ -109,3 +109,30 @@ def test_onepass_from_the_static_scratch_and_its_limit(xp):
     _lib.check(L.ppo_xp_returns_noalloc(buf.handle, ld.ctypes.data_as(C.c_void_p), N, _lib.GAE_ASSOC, b.ctypes.data_as(C.c_void_p)))
     np.testing.assert_array_equal(bits(a), bits(b))
     buf.close()
+
+
+@pytest.mark.parametrize("T,N", [(4096, 8192), (8192, 16384)])
+def test_onepass_with_more_workgroups_than_the_gpu_holds(xp, T, N):
+    """1 024 resp. 4 096 workgroups of 1 024 threads: at most 512 are resident at a time, so later super-chunks start only
+    when earlier ones have left.  The ticket order guarantees that a workgroup only waits for workgroups that already run;
+    this is the shape where a wrong order would hang (the waits are bounded: it would fail, not hang).  Checked against
+    the bit-exact sequential kernel within the K2 bound."""
+    import torch
+    buf = xp.ExperienceBuffer(N, 1, T)
+    g = torch.Generator(device="cuda").manual_seed(T + N)
+    z = torch.zeros
+    obs, act = z(N, 1, device="cuda"), z(N, dtype=torch.int64, device="cuda")
+    for t in range(T):
+        d = (torch.rand(N, device="cuda", generator=g) < 0.01).float()
+        buf.add_experience_device(obs, torch.randn(N, device="cuda", generator=g), act, torch.randn(N, device="cuda", generator=g), d, obs[:, 0])
+    buf.sync()
+    ld = (np.random.default_rng(1).random(N) < 0.02).astype(np.uint8)
+    seq = buf.returns(ld, algo=xp.GAE_SEQUENTIAL | xp.GAE_NO_PACK).clone()
+    one = buf.returns(ld, algo=xp.GAE_ASSOC | xp.GAE_NO_PACK).clone()
+    buf.sync()                                                   # reports a look-back that gave up
+    rel = ((one - seq).abs() / seq.abs().clamp(min=1.0)).max().item()
+    assert rel <= RTOL, rel
+    again = buf.returns(ld, algo=xp.GAE_ASSOC | xp.GAE_NO_PACK)
+    assert torch.equal(again.view(torch.int32), one.view(torch.int32))
+    buf.close()
+    torch.cuda.empty_cache()
