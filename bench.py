@@ -297,14 +297,14 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         step(i)
     barrier()
     fused = (not gae_only) and L.ppo_xp_pass_gather_kind(h) == 1
-    # timed region: HIP events only around the dominant kernel, and only on every 4th step (an event pair costs
+    # timed region: HIP events only around the dominant kernel, and only on every 8th step (an event pair costs
     # ~7 us of stream time: bracketing every launch would tax the very number it is there to explain)
     dom = "gae_scan" if gae_only else "gather"      # the dominant kernel of the step
     buf.prof_enable(False)
     buf.prof_collect()
     t0 = time.perf_counter()
     for i in range(steps):
-        if events and (i & 3) == 0:
+        if events and (i & 7) == 0:
             buf.prof_enable([dom])
             step(i)
             buf.prof_enable(False)
