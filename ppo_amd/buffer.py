@@ -112,6 +112,7 @@ class ExperienceBuffer:
             self._L.ppo_xp_destroy(self._h)       # synchronises the handle's stream first
             self._h = C.c_void_p()
             self._pass_perm = None                # a borrowed permutation is no longer read by anything
+            self._host_slots = None               # nor are host slots of a pipelined hand-off written any more
             self._ext_stream = None
 
     def __del__(self):

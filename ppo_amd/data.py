@@ -221,6 +221,9 @@ class ExperienceBatcherIterator:
                 self._host_pair = (HostBatch.pinned(self.batcher.batch_size, buf.obs_size),
                                    HostBatch.pinned(self.batcher.batch_size, buf.obs_size))
             slots = self._host_pair
+        # a download of minibatch k+1 may still be in flight when the consumer stops early and drops this iterator: the
+        # buffer keeps the two slots alive until its next pass (whose begin orders itself behind the copy stream) or close()
+        buf._host_slots = slots
         a, b = slots
         while True:
             rc = check(self.batcher._L.ppo_xp_pass_next_host_pipelined(buf.handle, C.byref(a._c), C.byref(b._c)))
