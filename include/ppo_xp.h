@@ -327,7 +327,9 @@ int ppo_xp_rnorm_state(ppo_xp_rnorm *r, float *mean, float *var, float *count, f
 
 void *ppo_xp_stream(const ppo_xp *h);            /* hipStream_t of the handle                */
 int ppo_xp_set_stream(ppo_xp *h, void *stream);  /* borrow a caller-owned stream instead     */
-int ppo_xp_sync(ppo_xp *h);                      /* hipStreamSynchronize                     */
+int ppo_xp_sync(ppo_xp *h);                      /* hipStreamSynchronize of the handle's stream (and of the copy stream of a
+                                                    pipelined host hand-off still in flight); also reports a one-launch
+                                                    associative scan whose bounded wait gave up (PPO_XP_EIO)            */
 int ppo_xp_device(const ppo_xp *h);
 
 /* Per-kernel HIP-event timing on the handle's stream (bench.py's roofline numbers).

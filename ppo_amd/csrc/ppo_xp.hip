@@ -1576,6 +1576,7 @@ int ppo_xp_set_stream(ppo_xp *h, void *stream) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   if (h->side_pending) HIP_TRY(hipStreamSynchronize(h->side));   // its join event stays valid for the new stream
   if (h->xfer) HIP_TRY(hipStreamSynchronize(h->xfer));
+  if ((hipStream_t)stream == h->stream) return 0;               // already there (the handle's own stream stays its own)
   if (h->own_stream) { (void)hipStreamDestroy(h->stream); h->own_stream = false; }
   h->stream = (hipStream_t)stream;
   return 0;
@@ -1585,6 +1586,7 @@ int ppo_xp_sync(ppo_xp *h) {
   if (!h) return fail(PPO_XP_EINVAL, "sync: handle is NULL");
   HIP_TRY(hipSetDevice(h->device));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->xfer) HIP_TRY(hipStreamSynchronize(h->xfer));     // a prefetched host minibatch still travelling
   return onepass_check(h);
 }
 

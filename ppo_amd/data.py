@@ -223,6 +223,8 @@ class ExperienceBatcherIterator:
             slots = self._host_pair
         # a download of minibatch k+1 may still be in flight when the consumer stops early and drops this iterator: the
         # buffer keeps the two slots alive until its next pass (whose begin orders itself behind the copy stream) or close()
+        if getattr(buf, "_host_slots", None) is not None and buf._host_slots is not slots:
+            buf.sync()              # an abandoned pass may still be writing the slots about to be dropped (ppo_xp_sync also waits for the copy stream)
         buf._host_slots = slots
         a, b = slots
         while True:

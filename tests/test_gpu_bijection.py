@@ -184,3 +184,25 @@ def test_library_gives_the_committed_vectors(xp):
         p = xp.ExperienceBatcher(buf, max(1, c["M"] // 2)).into_iter(seed=int(c["seed"]), bijection=True).perm()
         assert p[:16].tolist() == c["head"] and p[-4:].tolist() == c["tail"] and zlib.crc32(p.tobytes()) == c["crc32"]
         buf.close()
+
+
+def test_abandoned_pipelined_pass_and_set_stream_to_itself(xp, oracle):
+    """A consumer that stops after the first host minibatch leaves a download in flight: the next pass, new slots and a
+    ppo_xp_sync must all be ordered behind it; ppo_xp_set_stream with the stream the handle already uses changes nothing."""
+    g, o, r = both(xp, oracle, 16, 256, 64, 16, seed=2)
+    g.returns(r["last_dones"])
+    batcher = xp.ExperienceBatcher(g, 512)
+    it = batcher.into_iter(seed=1, bijection=True)
+    first = next(it.host_batches())
+    keep = first.observations.copy()
+    del it, first                                   # minibatch 1 may still be travelling into the second slot
+    it = batcher.into_iter(seed=1, bijection=True)
+    batches = [b.observations.copy() for b in it.host_batches()]
+    assert len(batches) == 8 and np.array_equal(batches[0], keep)
+    own = g.stream_ptr
+    g.use_stream(own)                               # same stream: must not destroy it
+    assert g.stream_ptr == own
+    it = batcher.into_iter(seed=1, bijection=True)
+    again = [b.observations.copy() for b in it.host_batches()]
+    assert all(np.array_equal(a, b) for a, b in zip(batches, again))
+    g.close()
