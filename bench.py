@@ -293,6 +293,16 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The set-up above is host work and a few small launches: the GPU is idle and takes ~0.2 s of load to reach its steady
+    # clocks (the first 25 steps of a cold run take 873 us, steady state is 859: tools/step_curve.py,
+    # profiles/r3/step_curve_cold_vs_warm.log).  The box's copy-rate measurement (context for the roofline)
+    # therefore runs HERE, for args.spinup_ms, right before the W warm-up steps and the K timed steps of the workload itself.
+    ceiling = None
+    if not args.no_copy_ceiling:
+        try:
+            ceiling = copy_ceiling(dev, min_ms=args.spinup_ms)
+        except Exception as e:          # context only: never costs the line
+            log(f"bench.py: copy ceiling not measured: {type(e).__name__}: {e}")
     for i in range(warmup):
         step(i)
     barrier()
@@ -382,7 +392,9 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         "config": {"workload": workload, "global_envs": world * N,
                    "parallelism": f"env-sharded x{world}" if ctx.multi else "single GPU",
                    "exchange": ((exchange + "/" + args.backend) if ctx.multi else "none"),
-                   "minibatches": "streamed one at a time into two slots" if buf.streaming else "all K gathered by one pass launch"},
+                   "minibatches": "streamed one at a time into two slots" if buf.streaming else "all K gathered by one pass launch",
+                   "gpu_spinup": (f"{ceiling['busy_ms']:.0f} ms of device copies (the copy_ceiling measurement) right before the {warmup} warm-up "
+                                  f"and {steps} timed steps: an idle GPU needs ~0.2 s of load to reach steady clocks" if ceiling else "none")},
         "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
         "alg_bytes_per_transition": step_bytes,
         "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "fused_gather_kernel" if fused else "obs_gather_kernel",
@@ -395,6 +407,7 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
         "perm_kind": (perm_kind if not (bijection and not fused and not gae_only) else
                       "keyed bijection, written out as an index array by one launch inside the timed step (split gather kernels read an array)"),
         "index_bytes": ib,
+        "copy_ceiling": ceiling,
         "rccl_ranks": rccl_ranks,
         "rank_ms_per_step": {"min": min(rank_ms), "max": max(rank_ms)},
         "exchange_exposed_us": exch_us,
@@ -416,26 +429,39 @@ def cited_traffic(config, kernel, perm):
     return {}
 
 
-def copy_ceiling(dev, nbytes=1 << 30, reps=10):
-    """The box's stream-copy rate (reported for context, the fraction stays against 8 TB/s):
-    device-to-device copy of 1 GiB, read + write bytes counted, torch events on the current stream."""
+def copy_ceiling(dev, nbytes=1 << 30, min_ms=600.0):
+    """The box's stream-copy rate (reported for context, the fraction stays against 8 TB/s): device-to-device
+    copies of 1 GiB, read + write bytes counted, torch events on the current stream.  measure() runs it right before the warm-up
+    steps, for at least `min_ms`: a GPU that has been idle (the set-up is host work and a few small launches) needs ~0.2 s of load to reach its
+    steady clocks - the first 25 steps of a cold run take 873 us, steady state is 859 (tools/step_curve.py,
+    profiles/r3/step_curve_cold_vs_warm.log) - so this measurement doubles as the spin-up; the W warm-up steps and the K
+    timed steps that follow are the workload's own, exactly as asked for."""
     import torch
     src = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     dst = torch.empty_like(src)
     src.zero_()
     for _ in range(3):
         dst.copy_(src)
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        dst.copy_(src)
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    torch.cuda.synchronize()
+    best, total_ms, reps = 0.0, 0.0, 0
+    t_start = time.perf_counter()
+    while (time.perf_counter() - t_start) * 1e3 < min_ms or reps < 10:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        best = max(best, 2 * nbytes / (ms * 1e-3) / 1e9)
+        total_ms += ms * 10
+        reps += 10
     del src, dst
-    return {"value": 2 * nbytes / (ms * 1e-3) / 1e9, "unit": "GB/s",
-            "what": "Tensor.copy_ of 1 GiB on one device (the runtime's device-to-device copy), read + write bytes; a hand-written copy kernel reaches ~6.3 TB/s on this part (profiles/r1 membench)"}
+    return {"value": best, "unit": "GB/s", "copies": reps, "busy_ms": total_ms,
+            "what": "Tensor.copy_ of 1 GiB on one device (the runtime's device-to-device copy), read + write bytes, best batch of 10; "
+                    "measured before the timed runs, where it also brings the idle GPU to its steady clocks; a hand-written copy "
+                    "kernel reaches ~6.3 TB/s on this part (profiles/r1 membench)"}
 
 
 def main():
@@ -459,6 +485,8 @@ def main():
     ap.add_argument("--streaming", action="store_true", help="gather minibatches one at a time into two slots (ppo_xp_set_streaming): "
                                                               "half the memory of a pass; not with --gpus > 1")
     ap.add_argument("--secondary-timeout", type=float, default=240.0, help="seconds the configs under 'also' may take before the headline is printed alone")
+    ap.add_argument("--no-copy-ceiling", action="store_true", help="skip the device-copy rate measurement that precedes the timed runs")
+    ap.add_argument("--spinup-ms", type=float, default=600.0, help="how long that measurement keeps the GPU busy (an idle GPU needs ~0.2 s of load to reach steady clocks)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -594,11 +622,8 @@ def main():
     if multi:
         dist.destroy_process_group()
     if rank == 0:
-        if world == 1:
-            try:
-                out["copy_ceiling"] = copy_ceiling(dev)
-            except Exception as e:          # context only: never costs the line
-                log(f"bench.py: copy ceiling not measured: {type(e).__name__}: {e}")
+        if out.get("copy_ceiling") is None:
+            out.pop("copy_ceiling", None)
         if not args.no_cpu_baseline and world == 1 and not gae_only:
             out["cpu_baseline"] = cpu_baseline(T, N, D, K)
         sys.stdout.flush()
