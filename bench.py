@@ -306,15 +306,16 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
     for i in range(warmup):
         step(i)
     barrier()
-    fused = (not gae_only) and L.ppo_xp_pass_gather_kind(h) == 1
-    # timed region: HIP events only around the dominant kernel, and only on every 8th step (an event pair costs
+    gkind = -1 if gae_only else L.ppo_xp_pass_gather_kind(h)
+    fused = gkind in (1, 2)
+    # timed region: HIP events only around the dominant kernel, and only on every 6th step (an event pair costs
     # ~7 us of stream time: bracketing every launch would tax the very number it is there to explain)
     dom = "gae_scan" if gae_only else "gather"      # the dominant kernel of the step
     buf.prof_enable(False)
     buf.prof_collect()
     t0 = time.perf_counter()
     for i in range(steps):
-        if events and (i & 7) == 0:
+        if events and i % 6 == min(3, steps - 1):   # not step 0 (unless it is the only one): the first launch after the barrier's host synchronisation starts on an idle queue
             buf.prof_enable([dom])
             step(i)
             buf.prof_enable(False)
@@ -397,7 +398,8 @@ def measure(ctx, cfg, steps, warmup, gae=None, events=True, breakdown=True, tuna
                                   f"and {steps} timed steps: an idle GPU needs ~0.2 s of load to reach steady clocks" if ceiling else "none")},
         "hbm_roofline_frac_whole_step": value * step_bytes / (world * HBM_PEAK_GBS * 1e9),
         "alg_bytes_per_transition": step_bytes,
-        "roofline": {"bound": "hbm", "kernel": "gae_scan_kernel" if gae_only else "fused_gather_kernel" if fused else "obs_gather_kernel",
+        "roofline": {"bound": "hbm", "kernel": ("gae_scan_kernel" if gae_only else "fused_gather_loop_kernel" if gkind == 2 else
+                                                    "fused_gather_kernel" if fused else "obs_gather_kernel"),
                      "achieved": achieved,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "alg_bytes_per_launch": M * dom_bytes, "avg_launch_us": g_avg_s * 1e6, "launches_timed": g_n},

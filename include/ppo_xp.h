@@ -254,7 +254,8 @@ int ppo_xp_pass_next_host_pipelined(ppo_xp *h, ppo_batch_host *cur, ppo_batch_ho
  * prefetch pass i+1's while pass i trains).  Any other pass_begin simply discards it. */
 int ppo_xp_shuffle_prefetch(ppo_xp *h, uint64_t seed);
 /* Which kernels gathered the current pass: 0 = scalar_gather_kernel + obs_gather_kernel, 1 = fused_gather_kernel
- * (rows and scalar streams in one launch; chosen by size, see the "fused" tunable), -1 = no pass.  For
+ * (rows and scalar streams in one launch; chosen by size, see the "fused" tunable), 2 = fused_gather_loop_kernel (the same
+ * with several row groups per workgroup: keyed-bijection passes, see "fused_iter"), -1 = no pass.  For
  * measurement harnesses that attribute bytes to kernels. */
 int ppo_xp_pass_gather_kind(const ppo_xp *h);
 /* Streaming mode: a pass keeps two B-row minibatch slots instead of the K*B-row slabs (which are a second copy of
@@ -355,7 +356,8 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * "fused" -1 (by size) / 0 / 1 (observation rows and scalar streams gathered by ONE kernel instead of two),
  * "fused_block" 256/512 (its workgroup size), "bij_mode" 0/1/2 (keyed-bijection passes: 0 = always write the index
  * array out first, 1 = one evaluation per output row handed to the row's threads through LDS, 2 = every thread evaluates
- * its own), "gae_onepass" -1 (by length) / 0 / 1 (PPO_XP_GAE_ASSOC as one launch), "op_l" 16/32/64 and "op_w" 2/4/8/16 (its
+ * its own), "fused_iter" 0 (by size) / 1 / 2 / 4 (keyed-bijection passes: row groups per workgroup of the fused gather; with 4 a
+ * workgroup covers 128 rows, issues its four row loads back to back and adds up one statistics partial), "gae_onepass" -1 (by length) / 0 / 1 (PPO_XP_GAE_ASSOC as one launch), "op_l" 16/32/64 and "op_w" 2/4/8/16 (its
  * chunk length and chunks per workgroup; only some pairs are built),
  * "overlap" 0/1 (1: with the two-kernel path, the observation rows are gathered on a side stream of the handle while
  * the scalar streams, statistics and standardisation run on its own; joined before the pass is handed out).

@@ -303,6 +303,75 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
   }
 }
 
+// The fused gather with ITER row groups per workgroup (keyed-bijection passes only): a workgroup of BS threads covers
+// RPW = ITER * BS/Q output rows - every thread issues its ITER independent 16-byte row loads back to back (there is no
+// index to wait for), then stores them; the first RPW threads evaluate perm(j) for the workgroup's rows, gather the rows'
+// scalar streams and add up ONE (sum, sum of squares) partial for all RPW rows.  With RPW = 256 a TGT minibatch has 1 024
+// partials instead of 8 192, so the standardise workgroups fold them themselves and reduce_partials_kernel is not launched.
+template <int BS, int ITER, bool NT, bool TAIL>
+__global__ __launch_bounds__(BS) void fused_gather_loop_kernel(FusedGatherArgs g) {
+  __shared__ uint32_t src_row[256];
+  __shared__ double red[4][2];
+  const unsigned Q = g.o.Q, rpi = (unsigned)BS >> g.o.qshift, rpw = g.rpw;      // rpw = ITER * rpi <= 256
+  const size_t row0 = (size_t)blockIdx.x * rpw;
+  const size_t KB = g.o.total >> g.o.qshift;
+  if (threadIdx.x < rpw && row0 + threadIdx.x < KB) {
+    size_t pos = g.o.row_base + row0 + threadIdx.x;
+    if (TAIL && pos >= g.o.tail_from) pos -= g.o.tail_shift;   // data.rs:121-122
+    src_row[threadIdx.x] = min(bij_perm(g.bij, (uint32_t)pos), (uint32_t)(g.o.M - 1));
+  }
+  __syncthreads();
+  const unsigned col = threadIdx.x & (Q - 1), rsub = threadIdx.x >> g.o.qshift;
+  f32x4 x[ITER];
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const unsigned r = it * rpi + rsub;
+    if (row0 + r < KB) {
+      const f32x4 *s = reinterpret_cast<const f32x4 *>(g.o.obs) + ((size_t)src_row[r] * Q + col);
+      x[it] = NT ? __builtin_nontemporal_load(s) : *s;
+    }
+  }
+  // scalar streams of row row0 + threadIdx.x: the first rpw threads (whole waves take part in the sums)
+  const unsigned nw = (rpw + 63u) >> 6;
+  if (threadIdx.x < nw * 64u) {
+    const size_t row = row0 + threadIdx.x;
+    const bool valid = threadIdx.x < rpw && row < KB;
+    float adv = 0.f;
+    if (valid) {
+      const uint32_t p = src_row[threadIdx.x];
+      const u32x2_t *rp = reinterpret_cast<const u32x2_t *>(g.s.rec + rec_static_idx(p));
+      const u32x2_t qs = *rp, qd = *(rp + 8);
+      const float nlp = __uint_as_float(qs.x), v = __uint_as_float(qd.x), ret = __uint_as_float(qd.y);
+      int64_t act = (int64_t)qs.y;
+      if (qs.y == kRecActEscape) act = g.s.actions[p];
+      adv = ret - v;                                          // data.rs:62
+      __builtin_nontemporal_store(v, g.s.val_out + row);
+      __builtin_nontemporal_store(nlp, g.s.nlp_out + row);
+      __builtin_nontemporal_store(ret, g.s.ret_out + row);
+      __builtin_nontemporal_store(act, g.s.act_out + row);
+      g.s.adv_out[row] = adv;
+    }
+    const double a = valid ? (double)adv : 0.0;
+    const double s1 = wave_sum(a), s2 = wave_sum(a * a);
+    if ((threadIdx.x & 63u) == 0) { red[threadIdx.x >> 6][0] = s1; red[threadIdx.x >> 6][1] = s2; }
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it) {
+    const unsigned r = it * rpi + rsub;
+    if (row0 + r < KB) {
+      f32x4 *d = reinterpret_cast<f32x4 *>(g.o.obs_out) + ((row0 + r) * Q + col);
+      if (NT) __builtin_nontemporal_store(x[it], d);
+      else *d = x[it];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t1 = 0.0, t2 = 0.0;
+    for (unsigned i = 0; i < nw; ++i) { t1 += red[i][0]; t2 += red[i][1]; }   // fixed order
+    g.s.partials[blockIdx.x] = make_double2(t1, t2);
+  }
+}
+
 // perm[j] = bij_perm(j) for j < M: the keyed bijection written out as an index array, for the gather kernels that
 // read one (rows wider than a workgroup, records beyond the Infinity Cache) and for ppo_xp_pass_perm_device / _host.
 __global__ __launch_bounds__(256) void bijection_perm_kernel(Bijection b, uint32_t *__restrict__ perm) {

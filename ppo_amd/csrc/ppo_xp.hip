@@ -182,9 +182,10 @@ struct ppo_xp {
   double *sums = nullptr; float *stats = nullptr; size_t sums_cap = 0;
   size_t pass_B = 0, pass_K = 0, pass_M = 0, pass_iter = 0;
   bool pass_active = false, pass_pending_finish = false;
-  int pass_kind = 0;         // 0: scalar_gather_kernel + obs_gather_kernel, 1: fused_gather_kernel
+  int pass_kind = 0;         // 0: scalar_gather_kernel + obs_gather_kernel, 1: fused_gather_kernel, 2: fused_gather_loop_kernel
   bool streaming = false;    // minibatches are gathered one at a time by pass_next into two alternating B-row slabs
   bool pass_streamed = false, pass_fusable = false;   // how the current pass was begun
+  unsigned pass_iter_rows = 1;                        // row groups per workgroup of the fused gather of the current pass
   // keyed-bijection pass (ppo_xp_pass_begin_bijection): perm(j) comes from `bij`; the index array h->perm is only
   // written when a kernel that reads one runs (split path) or when the caller asks for it
   Bijection bij{}; bool pass_bij = false, bij_inline = false, bij_perm_written = false;
@@ -205,7 +206,7 @@ struct ppo_xp {
   std::vector<ProfRec> prof_recs;
   std::vector<hipEvent_t> ev_pool;
   // tunables
-  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0, bij_mode = 1, gae_onepass = -1, op_l = 32, op_w = 16;
+  long gather_nt = 1, gather_block = 64, gae_unroll = 0, carry_waves = 16, gae_nt = 1, rec_nt = 0, out_nt = 1, gather_xcd = 0, summary_nt = 0, gae_waves = 0, fold_tiles = 256, gae_flat = 0, fused = -1, fused_block = 512, scalar_path = 0, overlap = 0, bij_mode = 1, gae_onepass = -1, op_l = 32, op_w = 16, fused_iter = 0;
 };
 
 namespace {
@@ -692,6 +693,13 @@ void launch_fused(ppo_xp *h, const FusedGatherArgs &f, dim3 grid, bool tail, int
   }
 }
 
+void launch_fused_loop(ppo_xp *h, const FusedGatherArgs &f, dim3 grid, bool tail, unsigned iter) {
+#define PPOXP_FL(IT) if (iter == IT) { if (tail) hipLaunchKernelGGL((fused_gather_loop_kernel<512, IT, true, true>), grid, dim3(512), 0, h->stream, f); \
+                                       else hipLaunchKernelGGL((fused_gather_loop_kernel<512, IT, true, false>), grid, dim3(512), 0, h->stream, f); return; }
+  PPOXP_FL(2) PPOXP_FL(4)
+#undef PPOXP_FL
+}
+
 // The keyed bijection of the current pass written out into h->perm (once per pass, on the handle's stream).
 int materialize_bijection(ppo_xp *h) {
   if (!h->pass_bij || h->bij_perm_written) return 0;
@@ -720,7 +728,9 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
   const bool whole = k0 == 0 && Kn == K;
   const unsigned Dq = (unsigned)h->D / 4;
   const unsigned FBq = (unsigned)h->fused_block;
-  const unsigned rpw = (Dq && FBq % Dq == 0) ? FBq / Dq : 0u;
+  const unsigned rpi = (Dq && FBq % Dq == 0) ? FBq / Dq : 0u;
+  const unsigned iter = h->pass_iter_rows;                     // row groups per workgroup (1 unless the looping kernel runs)
+  const unsigned rpw = rpi * iter;
   if (h->pass_fusable) {
     FusedGatherArgs f{};
     f.rpw = rpw;
@@ -739,7 +749,8 @@ int gather_range(ppo_xp *h, size_t k0, size_t Kn, const PassOut &o) {
       const dim3 grid((unsigned)blocks);
       const int bij = h->bij_inline ? (int)h->bij_mode : 0;
       f.bij = h->bij;
-      if (FBq == 256) launch_fused<256>(h, f, grid, tail, bij);
+      if (iter > 1) launch_fused_loop(h, f, grid, tail, iter);
+      else if (FBq == 256) launch_fused<256>(h, f, grid, tail, bij);
       else launch_fused<512>(h, f, grid, tail, bij);
       if (int rc = launch_check("fused_gather_kernel")) return rc;
     }
@@ -844,7 +855,18 @@ int pass_begin_body(ppo_xp *h, size_t B) {
   const bool bij_fused = h->pass_bij && h->bij_mode != 0 && rpw >= 32;
   const bool fusable = h->fused != 0 && h->D % 4 == 0 && (Dq & (Dq - 1)) == 0 && rpw >= 8 && rpw <= 64 &&
                        B % rpw == 0 && K <= 65535 && (h->fused == 1 || fits_mall || bij_fused);
-  const size_t tile_rows = fusable ? rpw : 256;
+  // looping fused kernel (bijection passes, 512-thread workgroups): ITER row groups per workgroup, when they tile the minibatch
+  // Measured (profiles/r3/ab_fused_row_groups.log): 4 row groups per workgroup win 1.1 - 1.6 % while the records sit in the
+  // Infinity Cache and the pass is long enough to matter (M = 2 M ... 8 M transitions: 222 against 225 us, 430 against 436,
+  // 847 against 857 at TGT), lose 1 us at C2 (0.5 M) and 3.4 % on the per-GPU shard of C5 (268 MB of records); 8 groups need
+  // 208 registers and lose 50 %.  "fused_iter" 0 = that rule, 1 / 2 / 4 force the choice.
+  unsigned iter = 1;
+  const long want_iter = h->fused_iter ? h->fused_iter : ((fits_mall && M >= (size_t(1) << 20)) ? 4 : 1);
+  if (fusable && h->pass_bij && h->bij_mode == 1 && FBq == 512 && want_iter > 1 && rpw * want_iter <= 256 &&
+      B % (rpw * (size_t)want_iter) == 0)
+    iter = (unsigned)want_iter;
+  h->pass_iter_rows = iter;
+  const size_t tile_rows = fusable ? (size_t)rpw * iter : 256;
   if (int rc = ensure_pass_buffers(h, K, B, tile_rows)) return rc;
   if (!h->have_rec) {
     ProfScope ps(h, PPO_XP_K_PACK);
@@ -853,7 +875,7 @@ int pass_begin_body(ppo_xp *h, size_t B) {
     if (int rc = launch_check("pack_records_kernel")) return rc;
     h->have_rec = true;
   }
-  h->pass_kind = fusable ? 1 : 0;
+  h->pass_kind = fusable ? (iter > 1 ? 2 : 1) : 0;
   h->pass_fusable = fusable;
   // keyed bijection: the fused kernel evaluates it in registers; the kernels that read an index array get it written
   // out first (one small launch, inside the pass)
@@ -1634,6 +1656,7 @@ int ppo_xp_set_tunable(ppo_xp *h, const char *name, long value) {
 #endif
   else if (n == "bij_mode" && value >= 0 && value <= 2) h->bij_mode = value;
   else if (n == "gae_onepass" && value >= -1 && value <= 1) h->gae_onepass = value;
+  else if (n == "fused_iter" && (value == 0 || value == 1 || value == 2 || value == 4)) h->fused_iter = value;
   else if (n == "op_l" && (value == 16 || value == 32 || value == 64)) h->op_l = value;
   else if (n == "op_w" && (value == 2 || value == 4 || value == 8 || value == 16)) h->op_w = value;
   else if (n == "rec_nt" && (value == 0 || value == 1)) h->rec_nt = value;

@@ -104,7 +104,7 @@ def test_tgt_size_bijection_and_rows(xp):
     ret = buf.returns(r["last_dones"].cpu().numpy()).clone()
     adv = buf.advantages().clone()
     it = xp.ExperienceBatcher(buf, B).into_iter(seed=123456789, bijection=True)
-    assert xp._lib.load().ppo_xp_pass_gather_kind(buf.handle) == 1
+    assert xp._lib.load().ppo_xp_pass_gather_kind(buf.handle) == 2       # fused, four row groups per workgroup (chosen by size)
     batches = [[t.clone() for t in (b.observations, b.actions, b.values, b.neglogps, b.returns, b.advantages)] for b in it]
     perm = xp.device_tensor(xp._lib.load().ppo_xp_pass_perm_device(buf.handle), (M,), torch.uint32, 0, buf).long()
     assert torch.equal(torch.sort(perm).values, torch.arange(M, device="cuda"))
@@ -206,3 +206,28 @@ def test_abandoned_pipelined_pass_and_set_stream_to_itself(xp, oracle):
     again = [b.observations.copy() for b in it.host_batches()]
     assert all(np.array_equal(a, b) for a, b in zip(batches, again))
     g.close()
+
+
+@pytest.mark.parametrize("T,N,B,streaming", [(32, 1024, 4096, False), (32, 1000, 4000 - 32, False), (16, 1024, 2048, True), (8, 512, 128, False)])
+def test_row_groups_per_workgroup(xp, T, N, B, streaming):
+    """fused_gather_loop_kernel (tunable fused_iter = 2 / 4; chosen by size from 2^20 transitions up): rows, actions and scalar
+    streams bit-identical to the array pass; the statistics are summed over 64- / 128-row tiles instead of 32-row ones, so the
+    standardised advantages may differ in the last bit of the fp32 mean / std: within 1e-6.  B = 3968 does not tile into 128
+    rows (falls back to one group) and gives an overlapping tail window with 2 groups."""
+    import torch
+    D = 64
+    buf = xp.ExperienceBuffer(N, D, T)
+    r = device_fill(buf, T, N, D, 6)
+    buf.returns(r["last_dones"].cpu().numpy())
+    buf.set_streaming(streaming)
+    buf.set_tunable("fused_iter", 1)
+    it, base = _collect(xp, buf, B, seed=33, bijection=True)
+    for iters in (2, 4, 0):
+        buf.set_tunable("fused_iter", iters)
+        _, got = _collect(xp, buf, B, seed=33, bijection=True)
+        assert len(got) == len(base)
+        for ma, mb in zip(got, base):
+            for x, y in zip(ma[:5], mb[:5]):
+                assert torch.equal(x.view(torch.int32) if x.dtype == torch.float32 else x, y.view(torch.int32) if y.dtype == torch.float32 else y)
+            assert (ma[5] - mb[5]).abs().max().item() <= 1e-6
+    buf.close()

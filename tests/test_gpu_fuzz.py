@@ -45,6 +45,7 @@ def test_random_configurations(xp, oracle, chunk):
         buf.set_tunable("fused", int(g.choice([-1, 0, 1])))
         buf.set_tunable("fused_block", int(g.choice([256, 512])))
         buf.set_tunable("bij_mode", int(g.choice([0, 1, 2])))
+        buf.set_tunable("fused_iter", int(g.choice([0, 1, 2, 4])))
         buf.set_tunable("overlap", int(g.choice([0, 1])))
         M = len(orc) * N
         perm = None

@@ -36,7 +36,7 @@ print(cfg, "gather kind", L.ppo_xp_pass_gather_kind(h), flush=True)
 
 def begin_array(i): _lib.check(L.ppo_xp_pass_begin_device(h, B, C.c_void_p(perm.data_ptr())))
 def begin_bij(i): _lib.check(L.ppo_xp_pass_begin_bijection(h, B, 1000 + i))
-variants = {"array": (begin_array, {}), "bij lds": (begin_bij, {"bij_mode": 1}), "bij per-thread": (begin_bij, {"bij_mode": 2}),
+variants = {"array": (begin_array, {}), "bij lds": (begin_bij, {"bij_mode": 1, "fused_iter": 1}), "bij auto": (begin_bij, {}), "bij per-thread": (begin_bij, {"bij_mode": 2}),
             "bij written out": (begin_bij, {"bij_mode": 0})}
 for a in sys.argv[3:]:
     name, rest = a.split(":", 1)
@@ -58,7 +58,7 @@ for rnd in range(rounds):
         if rnd:
             res[name].append({k: ms / max(n, 1) * 1e3 for k, (ms, n) in p.items() if n}); wall[name].append(dt * 1e6)
         for k_ in tun:
-            buf.set_tunable(k_, {"bij_mode": 1, "fused": -1, "fused_block": 512}.get(k_, 0))
+            buf.set_tunable(k_, {"bij_mode": 1, "fused": -1, "fused_block": 512, "fused_iter": 0, "gae_onepass": -1}.get(k_, 0))
 for name in variants:
     ks = sorted(res[name][0])
     print(f"{name:18s} step us median/min: {np.median(wall[name]):.1f}/{min(wall[name]):.1f} |",
