@@ -357,7 +357,7 @@ const char *ppo_xp_kernel_name(int kernel_id);
  * "fused_block" 256/512 (its workgroup size), "bij_mode" 0/1/2 (keyed-bijection passes: 0 = always write the index
  * array out first, 1 = one evaluation per output row handed to the row's threads through LDS, 2 = every thread evaluates
  * its own), "fused_iter" 0 (by size) / 1 / 2 / 4 (keyed-bijection passes: row groups per workgroup of the fused gather; with 4 a
- * workgroup covers 128 rows, issues its four row loads back to back and adds up one statistics partial), "gae_onepass" -1 (by length) / 0 / 1 (PPO_XP_GAE_ASSOC as one launch), "op_l" 16/32/64 and "op_w" 2/4/8/16 (its
+ * workgroup covers 128 rows, copies four row groups per thread (one load in flight at a time) and adds up one statistics partial), "gae_onepass" -1 (by length) / 0 / 1 (PPO_XP_GAE_ASSOC as one launch), "op_l" 16/32/64 and "op_w" 2/4/8/16 (its
  * chunk length and chunks per workgroup; only some pairs are built),
  * "overlap" 0/1 (1: with the two-kernel path, the observation rows are gathered on a side stream of the handle while
  * the scalar streams, statistics and standardisation run on its own; joined before the pass is handed out).

@@ -304,10 +304,13 @@ __global__ __launch_bounds__(BS) void fused_gather_kernel(FusedGatherArgs g) {
 }
 
 // The fused gather with ITER row groups per workgroup (keyed-bijection passes only): a workgroup of BS threads covers
-// RPW = ITER * BS/Q output rows - every thread issues its ITER independent 16-byte row loads back to back (there is no
-// index to wait for), then stores them; the first RPW threads evaluate perm(j) for the workgroup's rows, gather the rows'
-// scalar streams and add up ONE (sum, sum of squares) partial for all RPW rows.  With RPW = 256 a TGT minibatch has 1 024
-// partials instead of 8 192, so the standardise workgroups fold them themselves and reduce_partials_kernel is not launched.
+// RPW = ITER * BS/Q output rows - every thread loads its 16-byte element of each of the ITER groups, then stores them; the
+// first RPW threads evaluate perm(j) for the workgroup's rows, gather the rows' scalar streams and add up ONE (sum, sum of
+// squares) partial for all RPW rows: a quarter of the workgroups, barriers and partials at ITER = 4.
+// As compiled, each guarded load is waited for before the next one is issued (one row load in flight per thread; checked in
+// the ISA).  That is the shape that wins: the same kernel with the ITER loads issued back to back LOSES 3 % at TGT
+// (882 against 857 us per step with one row group; this kernel: 850), like every deeper-than-one-load shape measured in
+// round 1; a plain load-store-next loop ties, 256 rows per workgroup lose 4 % (profiles/r3/ab_fused_row_groups_isa.log).
 template <int BS, int ITER, bool NT, bool TAIL>
 __global__ __launch_bounds__(BS) void fused_gather_loop_kernel(FusedGatherArgs g) {
   __shared__ uint32_t src_row[256];
